@@ -1,0 +1,76 @@
+// Shared host/device helpers for libwvhash (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <algorithm>
+#include <cstdlib>
+#include <cstdio>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/wvhash.h"
+
+namespace wv {
+
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define WV_FAIL(code, ...)          \
+    do {                            \
+        ::wv::set_error(__VA_ARGS__); \
+        return (code);              \
+    } while (0)
+
+#define WV_REQUIRE(cond, ...)                      \
+    do {                                           \
+        if (!(cond)) WV_FAIL(WV_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+// Checks the launch itself (asynchronous execution errors surface at the caller's next sync).
+#define WV_CHECK_LAUNCH(what)                                                        \
+    do {                                                                             \
+        hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess) WV_FAIL(WV_EHIP, "%s: %s", what, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t align_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
+
+constexpr int kWave = 64;
+constexpr int kMaxLdsBytes = 160 * 1024;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// count of set bits of `mask` strictly below this lane
+__device__ __forceinline__ int mbcnt(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t n = __shfl_up(v, d, 64);
+        if (lane_id() >= d) v += n;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+}  // namespace wv

@@ -1,0 +1,420 @@
+// Fused Hamming distance + stable top-k ranking, list merge and average precision for gfx950.
+//
+// Reference: per query  hamm = 0.5*(B - q @ r.T); indices = torch.argsort(hamm)[:topk]
+// (accuracy_calculator.py:219-223) -- an O(N log N) comparison sort of a key with only B+1
+// distinct values.  Here: an exact counting sort in O(N), ties broken by ascending database
+// index (= torch.argsort(stable=True)).
+//
+// One workgroup (256 threads) ranks one query.  Thread t owns the CONTIGUOUS item range
+// [t*C, (t+1)*C), C = ceil(N/256), and a private column hist[bin][t] of an LDS table, so that
+//   phase 1  hist[d][t] += 1                     (conflict-free: bank = t mod 32 for every bin)
+//   scan     offs[d][t] = sum_{b<d} tot[b] + sum_{t'<t} hist[d][t']   (exclusive, bin-major)
+//   phase 2  pos = offs[d][t]++  -> idx[pos] = item      (only for d <= threshold bin T)
+// reproduces the stable order with no atomics, no sort and no inter-lane matching.  The
+// database is pre-transposed once per call into dbT[r][t] = code[t*C + r] so that the
+// per-thread contiguous ranges are read with fully coalesced loads.  The distance row is not
+// scattered at all: it is regenerated from the bin boundaries (sorted => run-length).
+#include "common.hpp"
+
+namespace wv {
+
+constexpr int kTopkThreads = 256;
+constexpr int kMaxBins = 129;  // nbits <= 128
+
+// ------------------------------------------------------------------------ item sources
+// CodeSource: items are database codes, distance = popcount(q ^ code), id = row + offset
+template <int WORDS>
+struct CodeSource {
+    const uint64_t *dbT;  // [C][256][WORDS]
+    uint64_t qw[WORDS];
+    int64_t idx_offset;
+    __device__ __forceinline__ int dist(int r, int t, int64_t) const
+    {
+        const uint64_t *p = dbT + ((int64_t)r * kTopkThreads + t) * WORDS;
+        int d = 0;
+        if constexpr (WORDS == 2) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(p);
+            d = __popcll(((uint64_t)v.x | ((uint64_t)v.y << 32)) ^ qw[0]) +
+                __popcll(((uint64_t)v.z | ((uint64_t)v.w << 32)) ^ qw[1]);
+        } else {
+#pragma unroll
+            for (int w = 0; w < WORDS; ++w) d += __popcll(p[w] ^ qw[w]);
+        }
+        return d;
+    }
+    __device__ __forceinline__ int32_t id(int64_t item) const { return (int32_t)(item + idx_offset); }
+};
+
+// ListSource: items are entries of G gathered per-shard lists for this query, in (shard, position)
+// order; distance and id are read back.
+struct ListSource {
+    const uint8_t *dist_q;   // + (g * Q + qi) * kin + p  handled by strides below
+    const int32_t *idx_q;
+    int64_t shard_stride;    // Q * kin
+    int kin;
+    __device__ __forceinline__ int64_t addr(int64_t item) const
+    {
+        const int64_t g = item / kin;
+        return g * shard_stride + (item - g * kin);
+    }
+    __device__ __forceinline__ int dist(int, int, int64_t item) const { return dist_q[addr(item)]; }
+    __device__ __forceinline__ int32_t id(int64_t item) const { return idx_q[addr(item)]; }
+};
+
+// RowSource: items are the entries of one stored distance-matrix row
+struct RowSource {
+    const uint8_t *row;
+    __device__ __forceinline__ int dist(int, int, int64_t item) const { return row[item]; }
+    __device__ __forceinline__ int32_t id(int64_t item) const { return (int32_t)item; }
+};
+
+// ------------------------------------------------------------------------ the ranking core
+// LDS: hist[nbins][256] u32, tot[nbins], base[nbins + 1], misc
+template <typename Source>
+__device__ __forceinline__ void rank_one_query(const Source &src, int64_t n_items, int C, int nbins,
+                                               int k, int32_t *__restrict__ idx_out,
+                                               uint8_t *__restrict__ dist_out, uint32_t *lds)
+{
+    uint32_t *hist = lds;                              // nbins * 256
+    uint32_t *tot = hist + nbins * kTopkThreads;       // kMaxBins
+    uint32_t *base = tot + kMaxBins;                   // kMaxBins + 1
+    uint32_t *misc = base + kMaxBins + 1;              // [0] = threshold bin T
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+
+    for (int i = tid; i < nbins * kTopkThreads; i += kTopkThreads) hist[i] = 0;
+    __syncthreads();
+
+    // ---- phase 1: private-column histogram
+    const int64_t first = (int64_t)tid * C;
+    for (int r = 0; r < C; ++r) {
+        const int64_t item = first + r;
+        if (item < n_items) {
+            const int d = src.dist(r, tid, item);
+            hist[d * kTopkThreads + tid] += 1;
+        }
+    }
+    __syncthreads();
+
+    // ---- per-bin totals (wave w takes bins w, w+4, ...)
+    for (int b = wv; b < nbins; b += kTopkThreads / 64) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(hist + b * kTopkThreads + 4 * lane);
+        const uint32_t s = wave_sum_u32(v.x + v.y + v.z + v.w);
+        if (lane == 0) tot[b] = s;
+    }
+    __syncthreads();
+
+    // ---- exclusive scan over bins (wave 0; up to 3 bins per lane covers 192 >= 129 bins)
+    if (wv == 0) {
+        uint32_t t0 = 0, t1 = 0, t2 = 0;
+        const int b0 = 3 * lane;
+        if (b0 < nbins) t0 = tot[b0];
+        if (b0 + 1 < nbins) t1 = tot[b0 + 1];
+        if (b0 + 2 < nbins) t2 = tot[b0 + 2];
+        const uint32_t incl = wave_incl_scan_u32(t0 + t1 + t2);
+        const uint32_t excl = incl - (t0 + t1 + t2);
+        if (b0 < nbins) base[b0] = excl;
+        if (b0 + 1 < nbins) base[b0 + 1] = excl + t0;
+        if (b0 + 2 < nbins) base[b0 + 2] = excl + t0 + t1;
+        if (lane == 63) base[nbins] = incl;  // = n_items
+        // threshold bin: first bin whose inclusive count reaches k
+        int cand = nbins;  // sentinel
+        if (b0 < nbins && excl + t0 >= (uint32_t)k) cand = b0;
+        else if (b0 + 1 < nbins && excl + t0 + t1 >= (uint32_t)k) cand = b0 + 1;
+        else if (b0 + 2 < nbins && excl + t0 + t1 + t2 >= (uint32_t)k) cand = b0 + 2;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) cand = min(cand, __shfl_xor(cand, d, 64));
+        if (lane == 0) misc[0] = (uint32_t)min(cand, nbins - 1);
+    }
+    __syncthreads();
+    const int T = (int)misc[0];
+
+    // ---- per-bin exclusive scan over threads, plus the bin base -> starting output offsets
+    for (int b = wv; b <= T; b += kTopkThreads / 64) {
+        uint4 v = *reinterpret_cast<const uint4 *>(hist + b * kTopkThreads + 4 * lane);
+        const uint32_t s = v.x + v.y + v.z + v.w;
+        const uint32_t excl = wave_incl_scan_u32(s) - s + base[b];
+        uint4 o;
+        o.x = excl;
+        o.y = excl + v.x;
+        o.z = o.y + v.y;
+        o.w = o.z + v.z;
+        *reinterpret_cast<uint4 *>(hist + b * kTopkThreads + 4 * lane) = o;
+    }
+    __syncthreads();
+
+    // ---- phase 2: stable placement of the items in bins <= T
+    for (int r = 0; r < C; ++r) {
+        const int64_t item = first + r;
+        if (item < n_items) {
+            const int d = src.dist(r, tid, item);
+            if (d <= T) {
+                const uint32_t pos = hist[d * kTopkThreads + tid]++;
+                if (pos < (uint32_t)k) idx_out[pos] = src.id(item);
+            }
+        }
+    }
+
+    // ---- distance row from the bin boundaries: dist[p] = b  with  base[b] <= p < base[b+1]
+    if (dist_out) {
+        for (int p = tid; p < k; p += kTopkThreads) {
+            int lo = 0, hi = nbins;  // invariant: base[lo] <= p < base[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (base[mid] <= (uint32_t)p) lo = mid;
+                else hi = mid;
+            }
+            dist_out[p] = (uint8_t)lo;
+        }
+    }
+}
+
+static inline size_t rank_lds_bytes(int nbins)
+{
+    return ((size_t)nbins * kTopkThreads + kMaxBins + kMaxBins + 1 + 4) * sizeof(uint32_t);
+}
+
+// ------------------------------------------------------------------------ kernels
+template <int WORDS>
+__global__ __launch_bounds__(kTopkThreads) void k_transpose_db(const uint64_t *__restrict__ db,
+                                                               uint64_t *__restrict__ dbT,
+                                                               int64_t N, int C)
+{
+    const int64_t total = (int64_t)C * kTopkThreads;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / kTopkThreads;
+        const int t = (int)(i - r * kTopkThreads);
+        const int64_t item = (int64_t)t * C + r;
+#pragma unroll
+        for (int w = 0; w < WORDS; ++w) dbT[i * WORDS + w] = item < N ? db[item * WORDS + w] : 0ull;
+    }
+}
+
+template <int WORDS>
+__global__ __launch_bounds__(kTopkThreads) void k_hamming_topk(const uint64_t *__restrict__ q,
+                                                               const uint64_t *__restrict__ dbT,
+                                                               int32_t *__restrict__ idx,
+                                                               uint8_t *__restrict__ dist, int64_t N,
+                                                               int C, int nbins, int k,
+                                                               int64_t idx_offset)
+{
+    extern __shared__ uint4 lds4[];
+    const int qi = blockIdx.x;
+    CodeSource<WORDS> src;
+    src.dbT = dbT;
+    src.idx_offset = idx_offset;
+#pragma unroll
+    for (int w = 0; w < WORDS; ++w) src.qw[w] = q[(int64_t)qi * WORDS + w];
+    rank_one_query(src, N, C, nbins, k, idx + (int64_t)qi * k, dist ? dist + (int64_t)qi * k : nullptr,
+                   reinterpret_cast<uint32_t *>(lds4));
+}
+
+__global__ __launch_bounds__(kTopkThreads) void k_topk_merge(const int32_t *__restrict__ idx_in,
+                                                             const uint8_t *__restrict__ dist_in,
+                                                             int G, int Q, int kin,
+                                                             int32_t *__restrict__ idx_out,
+                                                             uint8_t *__restrict__ dist_out, int k,
+                                                             int C, int nbins)
+{
+    extern __shared__ uint4 lds4[];
+    const int qi = blockIdx.x;
+    ListSource src;
+    src.dist_q = dist_in + (int64_t)qi * kin;
+    src.idx_q = idx_in + (int64_t)qi * kin;
+    src.shard_stride = (int64_t)Q * kin;
+    src.kin = kin;
+    rank_one_query(src, (int64_t)G * kin, C, nbins, k, idx_out + (int64_t)qi * k,
+                   dist_out ? dist_out + (int64_t)qi * k : nullptr, reinterpret_cast<uint32_t *>(lds4));
+}
+
+__global__ __launch_bounds__(kTopkThreads) void k_rank_from_dist(const uint8_t *__restrict__ dmat,
+                                                                 int64_t ld, int64_t N,
+                                                                 int32_t *__restrict__ idx,
+                                                                 uint8_t *__restrict__ dist, int k,
+                                                                 int C, int nbins)
+{
+    extern __shared__ uint4 lds4[];
+    const int qi = blockIdx.x;
+    RowSource src;
+    src.row = dmat + (int64_t)qi * ld;
+    rank_one_query(src, N, C, nbins, k, idx + (int64_t)qi * k, dist ? dist + (int64_t)qi * k : nullptr,
+                   reinterpret_cast<uint32_t *>(lds4));
+}
+
+// ------------------------------------------------------------------------ average precision
+// AP over a ranked list (accuracy_calculator.py:222-229): hits at 1-based ranks r_1 < r_2 < ...
+// give AP = mean_j (j / r_j); relevance = labels share a bit (label_comparison_fn :31-37).
+template <int LW>
+__global__ __launch_bounds__(256) void k_map_at_k(const int32_t *__restrict__ idx, int k,
+                                                  const uint64_t *__restrict__ qlab,
+                                                  const uint64_t *__restrict__ dblab, int lwords,
+                                                  float *__restrict__ ap, int32_t *__restrict__ nrel)
+{
+    __shared__ uint32_t wave_cnt[4];
+    __shared__ double wave_sum[4];
+    const int qi = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int32_t *list = idx + (int64_t)qi * k;
+    const int lw = LW > 0 ? LW : lwords;
+    uint64_t ql[LW > 0 ? LW : 1];
+    if constexpr (LW > 0) {
+#pragma unroll
+        for (int w = 0; w < LW; ++w) ql[w] = qlab[(int64_t)qi * LW + w];
+    }
+    uint32_t running = 0;
+    double acc = 0.0;
+    for (int p0 = 0; p0 < k; p0 += 256) {
+        const int p = p0 + tid;
+        bool rel = false;
+        if (p < k) {
+            const int32_t id = list[p];
+            if (id >= 0) {
+                const uint64_t *dl = dblab + (int64_t)id * lw;
+                if constexpr (LW > 0) {
+                    uint64_t any = 0;
+#pragma unroll
+                    for (int w = 0; w < LW; ++w) any |= dl[w] & ql[w];
+                    rel = any != 0;
+                } else {
+                    uint64_t any = 0;
+                    for (int w = 0; w < lw; ++w) any |= dl[w] & qlab[(int64_t)qi * lw + w];
+                    rel = any != 0;
+                }
+            }
+        }
+        const uint64_t mask = __ballot(rel);
+        if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        uint32_t before = running;
+        for (int w2 = 0; w2 < wv; ++w2) before += wave_cnt[w2];
+        const uint32_t block_total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        if (rel) {
+            const uint32_t j = before + (uint32_t)mbcnt(mask) + 1;  // this is the j-th hit
+            acc += (double)((float)j / (float)(p + 1));             // fp32 quotient like the reference
+        }
+        running += block_total;
+        __syncthreads();
+    }
+    acc = wave_sum_f64(acc);
+    if (lane == 0) wave_sum[wv] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        const double s = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+        ap[qi] = running ? (float)(s / (double)running) : 0.0f;
+        if (nrel) nrel[qi] = (int32_t)running;
+    }
+}
+
+static int set_lds_attr(const void *fn, size_t bytes, const char *what)
+{
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) WV_FAIL(WV_EHIP, "%s: hipFuncSetAttribute(%zu): %s", what, bytes, hipGetErrorString(e));
+    }
+    return WV_OK;
+}
+
+template <int WORDS>
+static int launch_topk(const uint64_t *q, const uint64_t *db, int32_t *idx, uint8_t *dist, int Q,
+                       int64_t N, int nbits, int k, int64_t idx_offset, void *ws, hipStream_t st)
+{
+    const int C = (int)ceil_div(N, kTopkThreads);
+    const int nbins = nbits + 1;
+    uint64_t *dbT = (uint64_t *)ws;
+    const int64_t total = (int64_t)C * kTopkThreads;
+    hipLaunchKernelGGL((k_transpose_db<WORDS>), dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 4096)),
+                       dim3(256), 0, st, db, dbT, N, C);
+    const size_t lds = rank_lds_bytes(nbins);
+    int rc = set_lds_attr(reinterpret_cast<const void *>(k_hamming_topk<WORDS>), lds, "hamming_topk");
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_hamming_topk<WORDS>), dim3(Q), dim3(kTopkThreads), lds, st, q, dbT, idx, dist,
+                       N, C, nbins, k, idx_offset);
+    WV_CHECK_LAUNCH("k_hamming_topk");
+    return WV_OK;
+}
+
+}  // namespace wv
+
+using namespace wv;
+
+extern "C" size_t wv_hamming_topk_workspace_bytes(int Q, int64_t N, int words, int k)
+{
+    (void)Q; (void)k;
+    if (N <= 0 || words <= 0) return 0;
+    return (size_t)ceil_div(N, kTopkThreads) * kTopkThreads * words * sizeof(uint64_t);
+}
+
+extern "C" int wv_hamming_topk(const uint64_t *q, const uint64_t *db, int32_t *idx, uint8_t *dist,
+                               int Q, int64_t N, int nbits, int k, int64_t idx_offset,
+                               void *workspace, size_t workspace_bytes, void *stream)
+{
+    WV_REQUIRE(q && db && idx, "hamming_topk: null buffer");
+    WV_REQUIRE(Q >= 0 && N >= 1, "hamming_topk: bad shape Q=%d N=%lld", Q, (long long)N);
+    WV_REQUIRE(nbits >= 1 && nbits <= 128, "hamming_topk: nbits=%d (supported: 1..128)", nbits);
+    WV_REQUIRE(k >= 1 && k <= N, "hamming_topk: k=%d must be in [1, N=%lld] (torch.topk raises too)", k,
+               (long long)N);
+    WV_REQUIRE(N + idx_offset <= 0x7fffffffLL && idx_offset >= 0, "hamming_topk: indices exceed int32");
+    const int words = (nbits + 63) / 64;
+    const size_t need = wv_hamming_topk_workspace_bytes(Q, N, words, k);
+    if (!workspace || workspace_bytes < need)
+        WV_FAIL(WV_ENOMEM, "hamming_topk: workspace %zu < %zu bytes", workspace_bytes, need);
+    if (Q == 0) return WV_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (words == 1) return launch_topk<1>(q, db, idx, dist, Q, N, nbits, k, idx_offset, workspace, st);
+    return launch_topk<2>(q, db, idx, dist, Q, N, nbits, k, idx_offset, workspace, st);
+}
+
+extern "C" int wv_topk_merge(const int32_t *idx_in, const uint8_t *dist_in, int G, int Q, int kin,
+                             int32_t *idx_out, uint8_t *dist_out, int k, int nbits, void *stream)
+{
+    WV_REQUIRE(idx_in && dist_in && idx_out, "topk_merge: null buffer");
+    WV_REQUIRE(G >= 1 && Q >= 0 && kin >= 1, "topk_merge: bad shape G=%d Q=%d kin=%d", G, Q, kin);
+    WV_REQUIRE(nbits >= 1 && nbits <= 128, "topk_merge: nbits=%d (supported: 1..128)", nbits);
+    WV_REQUIRE(k >= 1 && (int64_t)k <= (int64_t)G * kin, "topk_merge: k=%d > G*kin", k);
+    if (Q == 0) return WV_OK;
+    const int64_t items = (int64_t)G * kin;
+    const int C = (int)ceil_div(items, kTopkThreads);
+    const int nbins = nbits + 1;
+    const size_t lds = rank_lds_bytes(nbins);
+    int rc = set_lds_attr(reinterpret_cast<const void *>(k_topk_merge), lds, "topk_merge");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_topk_merge, dim3(Q), dim3(kTopkThreads), lds, (hipStream_t)stream, idx_in,
+                       dist_in, G, Q, kin, idx_out, dist_out, k, C, nbins);
+    WV_CHECK_LAUNCH("k_topk_merge");
+    return WV_OK;
+}
+
+extern "C" int wv_rank_from_dist(const uint8_t *dist_matrix, int64_t ld_dist, int Q, int64_t N,
+                                 int nbits, int32_t *idx, uint8_t *dist, int k, void *stream)
+{
+    WV_REQUIRE(dist_matrix && idx, "rank_from_dist: null buffer");
+    WV_REQUIRE(Q >= 0 && N >= 1 && ld_dist >= N, "rank_from_dist: bad shape");
+    WV_REQUIRE(nbits >= 1 && nbits <= 128, "rank_from_dist: nbits=%d (supported: 1..128)", nbits);
+    WV_REQUIRE(k >= 1 && k <= N && N <= 0x7fffffffLL, "rank_from_dist: k=%d must be in [1, N]", k);
+    if (Q == 0) return WV_OK;
+    const int C = (int)ceil_div(N, kTopkThreads);
+    const int nbins = nbits + 1;
+    const size_t lds = rank_lds_bytes(nbins);
+    int rc = set_lds_attr(reinterpret_cast<const void *>(k_rank_from_dist), lds, "rank_from_dist");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_rank_from_dist, dim3(Q), dim3(kTopkThreads), lds, (hipStream_t)stream,
+                       dist_matrix, ld_dist, N, idx, dist, k, C, nbins);
+    WV_CHECK_LAUNCH("k_rank_from_dist");
+    return WV_OK;
+}
+
+extern "C" int wv_map_at_k(const int32_t *idx, int Q, int k, const uint64_t *qlab,
+                           const uint64_t *dblab, int lwords, float *ap, int32_t *nrel, void *stream)
+{
+    WV_REQUIRE(idx && qlab && dblab && ap, "map_at_k: null buffer");
+    WV_REQUIRE(Q >= 0 && k >= 1 && lwords >= 1, "map_at_k: bad shape Q=%d k=%d lwords=%d", Q, k, lwords);
+    if (Q == 0) return WV_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (lwords == 1)
+        hipLaunchKernelGGL((k_map_at_k<1>), dim3(Q), dim3(256), 0, st, idx, k, qlab, dblab, lwords, ap, nrel);
+    else if (lwords == 2)
+        hipLaunchKernelGGL((k_map_at_k<2>), dim3(Q), dim3(256), 0, st, idx, k, qlab, dblab, lwords, ap, nrel);
+    else
+        hipLaunchKernelGGL((k_map_at_k<0>), dim3(Q), dim3(256), 0, st, idx, k, qlab, dblab, lwords, ap, nrel);
+    WV_CHECK_LAUNCH("k_map_at_k");
+    return WV_OK;
+}

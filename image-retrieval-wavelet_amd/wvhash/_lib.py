@@ -1,0 +1,120 @@
+"""ctypes binding of libwvhash.so (C ABI: include/wvhash.h).
+
+The product path has no CPU fallback: if the library is missing or fails to load, every op
+raises ``WvhashUnavailable`` -- it never silently computes on the host.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libwvhash.so")
+
+WV_DT_U8, WV_DT_F32, WV_DT_BF16 = 0, 1, 2
+WV_LAYOUT_NCHW, WV_LAYOUT_NHWC = 0, 1
+WV_METRIC_IP, WV_METRIC_L2 = 0, 1
+
+
+class WvhashUnavailable(RuntimeError):
+    pass
+
+
+class WvhashError(RuntimeError):
+    pass
+
+
+class HeadParams(ctypes.Structure):
+    _fields_ = [
+        ("embed_dim", ctypes.c_int), ("num_heads", ctypes.c_int), ("num_queries", ctypes.c_int),
+        ("num_tokens", ctypes.c_int), ("pool_mean", ctypes.c_int),
+        ("q_eff", ctypes.c_void_p), ("in_proj_w", ctypes.c_void_p), ("in_proj_b", ctypes.c_void_p),
+        ("attn_out_w", ctypes.c_void_p), ("attn_out_b", ctypes.c_void_p),
+        ("norm1_w", ctypes.c_void_p), ("norm1_b", ctypes.c_void_p),
+        ("mlp0_w", ctypes.c_void_p), ("mlp0_b", ctypes.c_void_p),
+        ("mlp2_w", ctypes.c_void_p), ("mlp2_b", ctypes.c_void_p),
+        ("out_w", ctypes.c_void_p), ("out_b", ctypes.c_void_p),
+        ("norm2_w", ctypes.c_void_p), ("norm2_b", ctypes.c_void_p),
+        ("ln_eps", ctypes.c_float),
+    ]
+
+
+_vp, _i, _i64, _sz, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
+_fp = ctypes.POINTER(ctypes.c_float)
+
+# name -> (restype, argtypes); must list every symbol include/wvhash.h declares
+SIGNATURES = {
+    "wv_last_error": (ctypes.c_char_p, []),
+    "wv_abi_version": (_i, []),
+    "wv_swt2d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "wv_swt2d_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _fp, _fp, _i, _vp, _sz, _vp]),
+    "wv_rawstack_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "wv_pack_bits": (_i, [_vp, _i64, _vp, _i64, _i, _i, _vp, _vp]),
+    "wv_bit_counts": (_i, [_vp, _i64, _i, _vp, _vp]),
+    "wv_hamming_dist": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _i, _vp]),
+    "wv_hamming_topk_workspace_bytes": (_sz, [_i, _i64, _i, _i]),
+    "wv_hamming_topk": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i64, _vp, _sz, _vp]),
+    "wv_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
+    "wv_rank_from_dist": (_i, [_vp, _i64, _i, _i64, _i, _vp, _vp, _i, _vp]),
+    "wv_map_at_k": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "wv_knn_float_workspace_bytes": (_sz, [_i, _i64, _i, _i]),
+    "wv_knn_float": (_i, [_vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "wv_band_attn_pool_workspace_bytes": (_sz, [ctypes.POINTER(HeadParams), _i]),
+    "wv_band_attn_pool": (_i, [ctypes.POINTER(HeadParams), _vp, _i, _vp, _vp, _sz, _vp]),
+    "wv_hash_tail": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),
+}
+
+_LIB = None
+
+
+def load():
+    """Load libwvhash.so (after torch, so that both share one HIP runtime)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise WvhashUnavailable(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C image-retrieval-wavelet_amd/csrc`. There is no CPU fallback.")
+    # torch ships its own libamdhip64 (same SONAME as /opt/rocm's): make sure it is the one mapped
+    hip_in_torch = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(hip_in_torch):
+        ctypes.CDLL(hip_in_torch, mode=ctypes.RTLD_GLOBAL)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise WvhashUnavailable(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise WvhashUnavailable("wvhash ops need a ROCm GPU (torch.cuda.is_available() is False); "
+                                "there is no CPU fallback in the product path")
+    return load()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().wv_last_error().decode(errors="replace")
+        if rc == -22:
+            raise ValueError(f"{what}: {msg}")
+        raise WvhashError(f"{what}: rc={rc}: {msg}")
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def host_floats(values):
+    arr = (ctypes.c_float * len(values))(*[float(v) for v in values])
+    return arr

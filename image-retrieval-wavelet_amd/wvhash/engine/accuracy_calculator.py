@@ -1,0 +1,256 @@
+"""GPU accuracy calculator with the method surface of
+/root/reference/main/engine/accuracy_calculator.py (CustomCalculator :16-349,
+get_accuracy_calculator :352-403).
+
+The reference subclasses pytorch_metric_learning's AccuracyCalculator and runs on CPU tensors; this
+class is self-contained (PML is not a dependency), keeps everything on the GPU and routes the
+arithmetic through libwvhash:
+  calc_hamming_dist       -> wv_hamming_dist        (:183-186)
+  calculate_maphashing    -> wv_hamming_topk + wv_map_at_k   (:203-231, the reported metric)
+  calculate_bit_balance / calculate_worst_bit_balance -> wv_bit_counts   (:188-200)
+  calculate_map           -> get_knn + wv_map_at_k  (:156-167, torchmetrics RetrievalMAP)
+Ranking ties are broken by ascending reference index (see engine/get_knn.py).
+"""
+import logging
+
+import torch
+
+from .. import _lib
+from . import hamming as H
+from .get_knn import get_knn, _to_gpu
+
+LOGGER = logging.getLogger("RETRIEVAL")
+
+_RECALL_KS = (1, 2, 4, 8, 10, 16, 20, 30, 32, 100, 1000)
+
+
+class CustomCalculator(object):
+
+    def __init__(self, include=(), exclude=(), avg_of_avgs=False, return_per_class=False, k=None,
+                 label_comparison_fn=None, device=None, knn_func=None, kmeans_func=None,
+                 with_faiss=True, distance_metric="l2", **kwargs):
+        if label_comparison_fn is not None or knn_func is not None or kmeans_func is not None:
+            raise NotImplementedError("custom label_comparison_fn / knn_func / kmeans_func are not supported")
+        if avg_of_avgs or return_per_class:
+            raise NotImplementedError("avg_of_avgs / return_per_class are not supported")
+        if not (isinstance(k, int) and k > 0) and k not in (None, "max_bin_count"):
+            raise ValueError("k must be a positive int, None or 'max_bin_count'")
+        self.k = k
+        self.num_top_k = k
+        self.with_faiss = with_faiss
+        self.distance_metric = distance_metric
+        # the reference pins the calculator to the CPU (main/engine/evaluate.py:76-81); here the
+        # ranking stage lives on the GPU whatever `device` says
+        self.requested_device = device
+        self.original_function_dict = {name[len("calculate_"):]: getattr(self, name)
+                                       for name in dir(self) if name.startswith("calculate_")}
+        self.check_primary_metrics(include, exclude)
+        self.original_function_dict = self.get_function_dict(include, exclude)
+        self.curr_function_dict = self.get_function_dict()
+        LOGGER.info(f"Initializing CustomCalculator with with_faiss={with_faiss} and "
+                    f"distance_metric={distance_metric} device: cuda (HIP)")
+
+    # ------------------------------------------------------------------ bookkeeping (PML surface)
+    @property
+    def device(self):
+        _lib.require_gpu()
+        return torch.device("cuda", torch.cuda.current_device())
+
+    def check_primary_metrics(self, include=(), exclude=()):
+        # unlike PML, names this implementation does not compute are tolerated in `exclude`
+        # (the reference's exclude lists name PML metrics such as NMI / AMI / mean_reciprocal_rank)
+        for m in include:
+            if m not in self.original_function_dict:
+                raise ValueError(f"{m} is not a metric computed by wvhash; valid: {sorted(self.original_function_dict)}")
+
+    def get_function_dict(self, include=(), exclude=()):
+        if len(include) == 0:
+            include = list(self.original_function_dict.keys())
+        included = [k for k in include if k not in exclude]
+        return {k: v for k, v in self.original_function_dict.items() if k in included}
+
+    def get_curr_metrics(self):
+        return [k for k in self.curr_function_dict.keys()]
+
+    def requires_knn(self):
+        return ["precision_at_1", "recall_classic", "rpr", "pr", "pr_rc", "map"] + \
+               [f"recall_at_{k}" for k in _RECALL_KS]
+
+    def requires_clustering(self):
+        return []
+
+    def description(self):
+        return "avg_of_avgs" if False else ""
+
+    def determine_k(self, bin_counts, num_reference_embeddings, embeddings_come_from_same_source):
+        self_count = int(embeddings_come_from_same_source)
+        if self.k == "max_bin_count":
+            return int(torch.max(bin_counts).item()) - self_count
+        if self.k is None:
+            return num_reference_embeddings - self_count
+        return self.k
+
+    # ------------------------------------------------------------------ relevance (:31-37)
+    def label_comparison_fn(self, query_labels, reference_labels):
+        if query_labels.ndim > 1 and reference_labels.ndim > 1:
+            if query_labels.dim() == 2 and reference_labels.dim() == 2:
+                return torch.matmul(query_labels.float(), reference_labels.t().float()) > 0
+            return (query_labels.float() * reference_labels.float()).sum(dim=-1) > 0
+        return query_labels.unsqueeze(1) == reference_labels
+
+    def _match_counts(self, query_labels, reference_labels, chunk=256):
+        """#references relevant to each query (what PML's get_label_match_counts feeds determine_k /
+        the lone-query mask with), chunked so the [Q, N] relevance matrix is never whole in memory."""
+        out = torch.empty(query_labels.shape[0], dtype=torch.long, device=query_labels.device)
+        for s in range(0, query_labels.shape[0], chunk):
+            out[s:s + chunk] = self.label_comparison_fn(query_labels[s:s + chunk], reference_labels).sum(dim=1)
+        return out
+
+    # ------------------------------------------------------------------ hashing primitives
+    def calc_hamming_dist(self, qB, rB):
+        """0.5 * (B - qB @ rB.T) for +-1 codes (:183-186) -> fp32 [Q, N] like the reference."""
+        qB, rB = _to_gpu(qB), _to_gpu(rB)
+        return H.hamming_dist(H.pack_codes(qB), H.pack_codes(rB)).float()
+
+    def per_bit_balance(self, reference):
+        reference = _to_gpu(reference)
+        nbits = reference.shape[1]
+        counts = H.bit_counts(H.pack_codes(reference, check=False), nbits)
+        frac_positive = counts.float() / float(reference.shape[0])
+        return 1.0 - 2.0 * (frac_positive - 0.5).abs()
+
+    def calculate_bit_balance(self, reference, **kwargs):
+        return self.per_bit_balance(reference).mean().item()
+
+    def calculate_worst_bit_balance(self, reference, **kwargs):
+        return self.per_bit_balance(reference).min().item()
+
+    def _ranked_lists(self, query, reference, topk):
+        nbits = reference.shape[1]
+        return H.hamming_topk(H.pack_codes(query), H.pack_codes(reference), nbits, topk, want_dist=False)[0]
+
+    def _average_precisions(self, idx, query_labels, reference_labels):
+        if query_labels.ndim == 1:  # class-id labels: one-hot them onto bits
+            classes = torch.unique(torch.cat([query_labels, reference_labels]))
+            query_labels = (query_labels.unsqueeze(1) == classes).float()
+            reference_labels = (reference_labels.unsqueeze(1) == classes).float()
+        return H.map_at_k(idx, H.pack_labels(query_labels), H.pack_labels(reference_labels))
+
+    def calculate_maphashing(self, query, query_labels, reference, reference_labels, topk,
+                             ref_includes_query=False, return_per_query=False, **kwargs):
+        while isinstance(topk, (tuple, list)):
+            topk = topk[0] if len(topk) else None
+        query, reference = _to_gpu(query), _to_gpu(reference)
+        query_labels, reference_labels = _to_gpu(query_labels), _to_gpu(reference_labels)
+        if topk == "max_bin_count":
+            topk = int(self._match_counts(reference_labels, reference_labels).max().item()) - int(ref_includes_query)
+        num_ref = reference.shape[0]
+        topk = num_ref if topk is None else min(int(topk), num_ref)  # gnd[0:topk] clips at N
+        num_query = query.shape[0]
+        if num_query == 0:
+            raise ZeroDivisionError("calculate_maphashing: no queries")
+        idx = self._ranked_lists(query, reference, topk)
+        ap, _ = self._average_precisions(idx, query_labels, reference_labels)
+        result = ap.double().sum().item() / num_query
+        if return_per_query:
+            return result, ap
+        return result
+
+    # ------------------------------------------------------------------ knn metrics
+    def calculate_map(self, query_labels, knn_indices, reference_labels, not_lone_query_mask, **kwargs):
+        """RetrievalMAP over the k-NN lists (:156-167): AP per kept query, no-hit queries count 0."""
+        ap, _ = self._average_precisions(knn_indices.int(), query_labels, reference_labels)
+        kept = ap[not_lone_query_mask]
+        return kept.double().mean().item() if kept.numel() else 0.0
+
+    def _knn_relevance(self, query_labels, knn_labels, k):
+        return self.label_comparison_fn(query_labels[:, None], knn_labels[:, :k]) if query_labels.ndim > 1 \
+            else (query_labels[:, None] == knn_labels[:, :k])
+
+    def recall_at_k(self, knn_labels, query_labels, k):
+        return self._knn_relevance(query_labels, knn_labels, k).any(1).float().mean().item()
+
+    def calculate_precision_at_1(self, knn_labels, query_labels, not_lone_query_mask, **kwargs):
+        rel = self._knn_relevance(query_labels, knn_labels, 1)[:, 0][not_lone_query_mask]
+        return rel.float().mean().item() if rel.numel() else 0.0
+
+    # ------------------------------------------------------------------ driver (:279-349)
+    def get_accuracy(self, query, query_labels, reference, reference_labels,
+                     embeddings_come_from_same_source, include=(), exclude=(), return_indices=False):
+        query, reference = _to_gpu(query), _to_gpu(reference)
+        query_labels, reference_labels = _to_gpu(query_labels), _to_gpu(reference_labels)
+
+        if query_labels.ndim == 1 or (query_labels.ndim == 2 and query_labels.size(1) == 1):
+            query_labels = query_labels.view(-1)
+            reference_labels = reference_labels.view(-1)
+
+        self.curr_function_dict = self.get_function_dict(include, exclude)
+
+        kwargs = {
+            "query": query,
+            "reference": reference,
+            "query_labels": query_labels,
+            "reference_labels": reference_labels,
+            "embeddings_come_from_same_source": embeddings_come_from_same_source,
+            "label_comparison_fn": self.label_comparison_fn,
+            "ref_includes_query": embeddings_come_from_same_source,
+            "topk": self.num_top_k,
+        }
+
+        knn_indices = None
+        if any(x in self.requires_knn() for x in self.get_curr_metrics()):
+            match_counts = self._match_counts(query_labels, reference_labels)
+            self_count = int(embeddings_come_from_same_source)
+            not_lone_query_mask = (match_counts - self_count) > 0
+            num_k = self.determine_k(match_counts, len(reference), embeddings_come_from_same_source)
+            knn_indices, knn_distances = get_knn(
+                reference, query, num_k, embeddings_come_from_same_source,
+                with_faiss=self.with_faiss, distance_metric=self.distance_metric,
+            )
+            if not bool(not_lone_query_mask.any()):
+                LOGGER.warning("None of the query labels are in the reference set.")
+            kwargs["knn_indices"] = knn_indices
+            kwargs["knn_distances"] = knn_distances
+            kwargs["not_lone_query_mask"] = not_lone_query_mask
+            if any(m.startswith("recall_at_") or m == "precision_at_1" for m in self.get_curr_metrics()):
+                kwargs["knn_labels"] = reference_labels[knn_indices[:, :1000]]
+
+        result = self._get_accuracy(self.curr_function_dict, **kwargs)
+        if return_indices:
+            return knn_indices, result
+        return result
+
+    def _get_accuracy(self, function_dict, **kwargs):
+        return {k: v(**kwargs) for k, v in function_dict.items()}
+
+
+def _make_recall(k):
+    def calculate(self, knn_labels, query_labels, **kwargs):
+        return self.recall_at_k(knn_labels, query_labels, k)
+    calculate.__name__ = f"calculate_recall_at_{k}"
+    return calculate
+
+
+for _k in _RECALL_KS:
+    setattr(CustomCalculator, f"calculate_recall_at_{_k}", _make_recall(_k))
+
+
+def get_accuracy_calculator(exclude_ranks=None, k=19581, with_AP=True, **kwargs):
+    """Same exclude-list construction as the reference (:352-403)."""
+    caller_exclude = kwargs.pop('exclude', [])
+    exclude = list(caller_exclude)
+    if with_AP:
+        exclude.extend(['NMI', 'AMI'])
+    else:
+        exclude.extend(['NMI', 'AMI', 'mean_average_precision', 'mean_average_precision_at_r'])
+    if exclude_ranks:
+        for r in exclude_ranks:
+            exclude.append(f'recall_at_{r}')
+    base_exclude = [
+        "mean_reciprocal_rank", "precision_at_1", "recall_at_1", "recall_at_1000", "recall_at_100",
+        "recall_at_10", "recall_at_16", "recall_at_20", "recall_at_30", "recall_at_32",
+        "recall_at_4", "recall_at_8", "recall_at_2", "recall_at_10", "pr_rc_hashing",
+    ]
+    exclude = sorted(set(exclude) | set(base_exclude))
+    LOGGER.info(f"Excluding metrics: {exclude}")
+    return CustomCalculator(exclude=exclude, k=k, **kwargs)

@@ -1,0 +1,79 @@
+"""k-NN of queries vs references on the GPU -- same signature and return order as
+/root/reference/main/engine/get_knn.py:9-24.
+
+* ``distance_metric in ("hamming", "cosine")``: scores = q @ r.T, top-k largest (get_knn.py:63-66).
+  +-1 codes take the bit-packed XOR/popcount kernel; the returned "distances" are the same inner
+  products the reference returns (nbits - 2 * hamming).  Anything else takes the fp32 kernel.
+* otherwise: true L2 (torch.cdist semantics, get_knn.py:67-69), top-k smallest.
+Ties are returned in ascending reference index (the reference's order inside a tie is whatever
+torch.topk / faiss produce: implementation-defined).  ``with_faiss`` is accepted and ignored: both of
+the reference's back-ends are replaced by the same HIP kernels.
+"""
+import ctypes
+import logging
+
+import torch
+
+from .. import _lib
+from . import hamming as H
+
+LOGGER = logging.getLogger("RETRIEVAL")
+
+
+def _to_gpu(x):
+    if not torch.is_tensor(x):
+        x = torch.as_tensor(x)
+    if not x.is_cuda:
+        _lib.require_gpu()
+        x = x.cuda(non_blocking=True)
+    return x
+
+
+def _is_pm1(x):
+    return bool(((x == 1) | (x == -1)).all().item())
+
+
+def knn_float(references, queries, num_k, metric):
+    lib = _lib.require_gpu()
+    q = queries.float().contiguous()
+    r = references.float().contiguous()
+    Q, D = q.shape
+    N = r.shape[0]
+    idx = torch.empty((Q, num_k), dtype=torch.int32, device=q.device)
+    val = torch.empty((Q, num_k), dtype=torch.float32, device=q.device)
+    ws_bytes = lib.wv_knn_float_workspace_bytes(Q, N, D, num_k)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=q.device)
+    with torch.cuda.device(q.device):
+        rc = lib.wv_knn_float(_lib.ptr(q), _lib.ptr(r), Q, N, D, metric, num_k, _lib.ptr(idx), _lib.ptr(val),
+                              _lib.ptr(ws), ctypes.c_size_t(ws_bytes), _lib.stream_ptr())
+        _lib.check(rc, "wv_knn_float")
+    return val, idx
+
+
+def get_knn(references, queries, num_k, embeddings_come_from_same_source, with_faiss=True, distance_metric="l2"):
+    num_k += embeddings_come_from_same_source
+
+    LOGGER.info("running k-nn with k=%d" % num_k)
+    LOGGER.info("embedding dimensionality is %d" % references.size(-1))
+    LOGGER.info(f"distance metric: {distance_metric}")
+
+    references, queries = _to_gpu(references), _to_gpu(queries)
+    if num_k > references.shape[0]:
+        raise RuntimeError(f"selected index k out of range (k={num_k}, references={references.shape[0]})")
+
+    nbits = references.shape[1]
+    if distance_metric == "hamming" and nbits <= 128 and _is_pm1(references) and _is_pm1(queries):
+        idx, dist = H.hamming_topk(H.pack_codes(queries, check=False), H.pack_codes(references, check=False),
+                                   nbits, num_k)
+        distances = float(nbits) - 2.0 * dist.float()
+        indices = idx.long()
+    elif distance_metric in ["hamming", "cosine"]:
+        distances, idx = knn_float(references, queries, num_k, _lib.WV_METRIC_IP)
+        indices = idx.long()
+    else:
+        distances, idx = knn_float(references, queries, num_k, _lib.WV_METRIC_L2)
+        indices = idx.long()
+
+    if embeddings_come_from_same_source:
+        return indices[:, 1:], distances[:, 1:]
+    return indices, distances

@@ -1,0 +1,160 @@
+"""Device-side Hamming retrieval primitives (thin wrappers over the C ABI, include/wvhash.h).
+
+Codes are +-1 fp32 rows in the reference (torch.sign output, multi_dino_attention.py:833); here
+they are packed 64 per int64 word once and stay on the GPU.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+
+
+def _words(nbits):
+    return (nbits + 63) // 64
+
+
+def _pack(src, mode, check, what):
+    lib = _lib.require_gpu()
+    if src.dim() != 2:
+        raise ValueError(f"{what}: expected a 2-D tensor, got {tuple(src.shape)}")
+    src = src.to(device=_device_of(src), dtype=torch.float32)
+    if src.stride(1) != 1:
+        src = src.contiguous()
+    rows, nbits = src.shape
+    out = torch.empty((rows, _words(nbits)), dtype=torch.int64, device=src.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=src.device) if check else None
+    if rows:
+        with torch.cuda.device(src.device):
+            rc = lib.wv_pack_bits(_lib.ptr(src), src.stride(0), _lib.ptr(out), rows, nbits, mode,
+                                  _lib.ptr(flag), _lib.stream_ptr())
+            _lib.check(rc, "wv_pack_bits")
+    if check and rows and int(flag.item()):
+        if mode == 0:
+            raise ValueError(f"{what}: codes must be exactly +1/-1 to be bit-packed (found 0, NaN or another "
+                             "value, e.g. sign(0)); use the float path get_knn(..., distance_metric='cosine')")
+        raise ValueError(f"{what}: labels must be non-negative multi-hot values to be bit-packed")
+    return out
+
+
+def _device_of(t):
+    if t.is_cuda:
+        return t.device
+    _lib.require_gpu()
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def pack_codes(codes, check=True):
+    """[N, nbits] +-1 -> int64 [N, ceil(nbits/64)], bit j of word w = codes[:, 64w+j] > 0."""
+    return _pack(codes, 0, check, "pack_codes")
+
+
+def pack_labels(labels, check=True):
+    """[N, Lc] multi-hot (>= 0) -> int64 [N, ceil(Lc/64)]."""
+    if labels.dim() == 1:
+        raise ValueError("pack_labels: 1-D class-id labels are compared with ==, not packed")
+    return _pack(labels, 1, check, "pack_labels")
+
+
+def bit_counts(packed, nbits):
+    lib = _lib.require_gpu()
+    counts = torch.empty(nbits, dtype=torch.int32, device=packed.device)
+    with torch.cuda.device(packed.device):
+        rc = lib.wv_bit_counts(_lib.ptr(packed), packed.shape[0], nbits, _lib.ptr(counts), _lib.stream_ptr())
+        _lib.check(rc, "wv_bit_counts")
+    return counts
+
+
+def hamming_dist(q_packed, db_packed):
+    """-> uint8 [Q, N] view (row pitch padded to 64 bytes so every row store is 16-B aligned)."""
+    lib = _lib.require_gpu()
+    Q, words = q_packed.shape
+    N = db_packed.shape[0]
+    if db_packed.shape[1] != words:
+        raise ValueError("hamming_dist: query and database code widths differ")
+    ld = (N + 63) // 64 * 64
+    buf = torch.empty((Q, ld), dtype=torch.uint8, device=q_packed.device)
+    if Q and N:
+        with torch.cuda.device(q_packed.device):
+            rc = lib.wv_hamming_dist(_lib.ptr(q_packed), _lib.ptr(db_packed), _lib.ptr(buf), ld, Q, N, words,
+                                     _lib.stream_ptr())
+            _lib.check(rc, "wv_hamming_dist")
+    return buf[:, :N]
+
+
+class TopkWorkspace:
+    """Reusable scratch for hamming_topk (the transposed database image)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+def hamming_topk(q_packed, db_packed, nbits, k, idx_offset=0, workspace=None, want_dist=True):
+    """k nearest database rows per query, ascending (distance, index).
+    -> (idx int32 [Q,k], dist uint8 [Q,k] or None)."""
+    lib = _lib.require_gpu()
+    Q, words = q_packed.shape
+    N = db_packed.shape[0]
+    if db_packed.shape[1] != words or words != _words(nbits):
+        raise ValueError("hamming_topk: code widths do not match nbits")
+    dev = q_packed.device
+    idx = torch.empty((Q, k), dtype=torch.int32, device=dev)
+    dist = torch.empty((Q, k), dtype=torch.uint8, device=dev) if want_dist else None
+    ws_bytes = lib.wv_hamming_topk_workspace_bytes(Q, N, words, k)
+    ws = (workspace or TopkWorkspace()).get(ws_bytes, dev)
+    with torch.cuda.device(dev):
+        rc = lib.wv_hamming_topk(_lib.ptr(q_packed), _lib.ptr(db_packed), _lib.ptr(idx), _lib.ptr(dist), Q, N,
+                                 nbits, k, idx_offset, _lib.ptr(ws), ctypes.c_size_t(ws.numel()),
+                                 _lib.stream_ptr())
+        _lib.check(rc, "wv_hamming_topk")
+    return idx, dist
+
+
+def topk_merge(idx_in, dist_in, k, nbits):
+    """[G,Q,kin] per-shard lists (contiguous row shards in rank order) -> global [Q,k]."""
+    lib = _lib.require_gpu()
+    G, Q, kin = idx_in.shape
+    idx_in, dist_in = idx_in.contiguous(), dist_in.contiguous()
+    idx = torch.empty((Q, k), dtype=torch.int32, device=idx_in.device)
+    dist = torch.empty((Q, k), dtype=torch.uint8, device=idx_in.device)
+    with torch.cuda.device(idx_in.device):
+        rc = lib.wv_topk_merge(_lib.ptr(idx_in), _lib.ptr(dist_in), G, Q, kin, _lib.ptr(idx), _lib.ptr(dist), k,
+                               nbits, _lib.stream_ptr())
+        _lib.check(rc, "wv_topk_merge")
+    return idx, dist
+
+
+def rank_from_dist(dist_matrix, nbits, k):
+    lib = _lib.require_gpu()
+    Q, N = dist_matrix.shape
+    if dist_matrix.stride(1) != 1:
+        dist_matrix = dist_matrix.contiguous()
+    idx = torch.empty((Q, k), dtype=torch.int32, device=dist_matrix.device)
+    dist = torch.empty((Q, k), dtype=torch.uint8, device=dist_matrix.device)
+    with torch.cuda.device(dist_matrix.device):
+        rc = lib.wv_rank_from_dist(_lib.ptr(dist_matrix), dist_matrix.stride(0), Q, N, nbits, _lib.ptr(idx),
+                                   _lib.ptr(dist), k, _lib.stream_ptr())
+        _lib.check(rc, "wv_rank_from_dist")
+    return idx, dist
+
+
+def map_at_k(idx, qlab_packed, dblab_packed):
+    """Average precision per query over its ranked list -> (ap float32 [Q], nrel int32 [Q])."""
+    lib = _lib.require_gpu()
+    Q, k = idx.shape
+    lw = qlab_packed.shape[1]
+    if dblab_packed.shape[1] != lw:
+        raise ValueError("map_at_k: label widths differ")
+    ap = torch.empty(Q, dtype=torch.float32, device=idx.device)
+    nrel = torch.empty(Q, dtype=torch.int32, device=idx.device)
+    if Q:
+        with torch.cuda.device(idx.device):
+            rc = lib.wv_map_at_k(_lib.ptr(idx.contiguous()), Q, k, _lib.ptr(qlab_packed), _lib.ptr(dblab_packed),
+                                 lw, _lib.ptr(ap), _lib.ptr(nrel), _lib.stream_ptr())
+            _lib.check(rc, "wv_map_at_k")
+    return ap, nrel

@@ -1,0 +1,6 @@
+from .custom_transforms import SWTTransform, DWTTransform, RawStackTransform, BaseWaveletTransform
+from .functional import swt2d, rawstack
+from .wavelets import get_filters, wavelist
+
+__all__ = ["SWTTransform", "DWTTransform", "RawStackTransform", "BaseWaveletTransform", "swt2d",
+           "rawstack", "get_filters", "wavelist"]

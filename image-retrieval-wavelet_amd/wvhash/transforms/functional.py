@@ -1,0 +1,80 @@
+"""Batched device-side wavelet transforms (the HIP path behind the plugin classes)."""
+import ctypes
+
+import torch
+
+from .. import _lib
+from .wavelets import get_filters
+
+
+def _layout_and_shape(x, channels_last):
+    if x.dim() != 4:
+        raise ValueError(f"expected a 4-D batch, got shape {tuple(x.shape)}")
+    if channels_last:
+        B, H, W, C = x.shape
+        return _lib.WV_LAYOUT_NHWC, B, C, H, W
+    B, C, H, W = x.shape
+    return _lib.WV_LAYOUT_NCHW, B, C, H, W
+
+
+def _in_dtype(x):
+    if x.dtype == torch.uint8:
+        return _lib.WV_DT_U8
+    if x.dtype == torch.float32:
+        return _lib.WV_DT_F32
+    raise TypeError(f"images must be uint8 (0..255) or float32 (already scaled), got {x.dtype}")
+
+
+def swt2d(x, wavelet="haar", level=1, channels_last=False, out_dtype=torch.float32):
+    """Batch of images on the GPU -> [B, C, 4, H, W] level-`level` sub-bands (cA, cH, cV, cD).
+
+    Same numbers as stacking ``SWTTransform(level, wavelet)(img)`` of the reference
+    (custom_transforms.py:145-166) over the batch: uint8 input is divided by 255 in fp32,
+    float32 input is used as is.  ``channels_last`` = the batch is [B, H, W, C] (PIL layout).
+    """
+    lib = _lib.require_gpu()
+    if not x.is_cuda:
+        raise ValueError("swt2d: input must live on the GPU (no CPU path in the product)")
+    x = x.contiguous()
+    layout, B, C, H, W = _layout_and_shape(x, channels_last)
+    lo, hi = get_filters(wavelet)
+    if out_dtype == torch.float32:
+        odt = _lib.WV_DT_F32
+    elif out_dtype == torch.bfloat16:
+        odt = _lib.WV_DT_BF16
+    else:
+        raise TypeError("out_dtype must be float32 or bfloat16")
+    out = torch.empty((B, C, 4, H, W), dtype=out_dtype, device=x.device)
+    if B == 0:
+        return out
+    if H % (1 << level) or W % (1 << level):
+        # PyWavelets' message for swt2 on a bad size
+        raise ValueError(f"Length of data must be even along the transform axis / divisible by 2**level; "
+                         f"got {H}x{W} at level {level}")
+    ws_bytes = lib.wv_swt2d_workspace_bytes(B, C, H, W, level, len(lo))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+    with torch.cuda.device(x.device):
+        for b0 in range(0, B, 65535):
+            b1 = min(B, b0 + 65535)
+            rc = lib.wv_swt2d_forward(_lib.ptr(x[b0:b1]), _in_dtype(x), layout, _lib.ptr(out[b0:b1]), odt,
+                                      b1 - b0, C, H, W, level, _lib.host_floats(lo), _lib.host_floats(hi),
+                                      len(lo), _lib.ptr(ws), ctypes.c_size_t(ws_bytes), _lib.stream_ptr())
+            _lib.check(rc, "wv_swt2d_forward")
+    return out
+
+
+def rawstack(x, copies=4, channels_last=False):
+    """[B,C,H,W] -> [B,C,copies,H,W] identical planes (RawStackTransform, :172-188)."""
+    lib = _lib.require_gpu()
+    if not x.is_cuda:
+        raise ValueError("rawstack: input must live on the GPU")
+    x = x.contiguous()
+    layout, B, C, H, W = _layout_and_shape(x, channels_last)
+    out = torch.empty((B, C, copies, H, W), dtype=torch.float32, device=x.device)
+    if B == 0:
+        return out
+    with torch.cuda.device(x.device):
+        rc = lib.wv_rawstack_forward(_lib.ptr(x), _in_dtype(x), layout, _lib.ptr(out), _lib.WV_DT_F32,
+                                     B, C, H, W, copies, _lib.stream_ptr())
+        _lib.check(rc, "wv_rawstack_forward")
+    return out

@@ -1,0 +1,190 @@
+/*
+ * wvhash.h -- C ABI of libwvhash.so, the MI355X (gfx950) implementation of the
+ * wavelet-hashing retrieval hot path of ArseneAmoya/image-retrieval-wavelet.
+ *
+ * The reference is pure Python; its FFI boundary for this path is "Python calls into a native
+ * wheel" (PyWavelets for the transform, ATen / faiss for the ranking, ATen for the attention
+ * head).  Each entry point below names the reference call site it replaces (file:line under
+ * /root/reference) -- the ctypes binding a maintainer would add is in INTEGRATION.md.
+ *
+ * Conventions
+ *   - Every function returns 0 (WV_OK) or a negative errno-style code; nothing throws across
+ *     the ABI.  wv_last_error() returns a per-thread message for the last failure.
+ *   - All pointers are DEVICE pointers unless the name says host.  The caller owns every
+ *     buffer; the library allocates nothing.  Scratch comes from the caller, sized by the
+ *     matching *_workspace_bytes() query.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls only enqueue
+ *     work: no hidden synchronisation, no host<->device copies.
+ *   - Thread-safe and re-entrant; no global mutable state except the per-thread error string.
+ *   - One process per GPU; the current HIP device of the calling thread is used.
+ */
+#ifndef WVHASH_H
+#define WVHASH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WV_OK 0
+#define WV_EINVAL (-22)  /* bad argument (message says which) */
+#define WV_ENOMEM (-12)  /* workspace too small */
+#define WV_ENOTSUP (-95) /* shape outside what the kernels implement */
+#define WV_EHIP (-5)     /* HIP runtime error at launch */
+
+/* element types of image / coefficient buffers */
+#define WV_DT_U8 0
+#define WV_DT_F32 1
+#define WV_DT_BF16 2
+
+/* image memory layouts */
+#define WV_LAYOUT_NCHW 0 /* [B][C][H][W]  (torch, after ToTensor-style permute) */
+#define WV_LAYOUT_NHWC 1 /* [B][H][W][C]  (PIL / numpy, what np.array(img) yields) */
+
+const char *wv_last_error(void);
+int wv_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Stationary wavelet transform.
+ * Replaces pywt.swt2(channel, wavelet, level)[0] + np.stack + the /255 scaling of
+ *   main/transforms/custom_transforms.py:145-157 (BaseWaveletTransform.__call__) and
+ *   :163-166 (SWTTransform._apply_wavelet), for a whole batch at once.
+ * in : [B,C,H,W] or [B,H,W,C]; u8 values are divided by 255.0f, f32 values are used as is.
+ * out: [B][C][4][H][W], band order cA, cH, cV, cD of level `level` (coarsest) only.
+ * H and W must be multiples of 2^level (PyWavelets raises otherwise -> WV_EINVAL).
+ * dec_lo / dec_hi: HOST pointers to `flen` decomposition taps (PyWavelets order).
+ * workspace: needed only for shapes the tiled kernel does not cover (query below; may be 0).
+ * ------------------------------------------------------------------------------------------ */
+size_t wv_swt2d_workspace_bytes(int B, int C, int H, int W, int level, int flen);
+int wv_swt2d_forward(const void *in, int in_dtype, int in_layout, void *out, int out_dtype, int B,
+                     int C, int H, int W, int level, const float *dec_lo, const float *dec_hi,
+                     int flen, void *workspace, size_t workspace_bytes, void *stream);
+
+/* RawStackTransform (custom_transforms.py:172-188): `copies` identical planes per channel.
+ * out: [B][C][copies][H][W]. */
+int wv_rawstack_forward(const void *in, int in_dtype, int in_layout, void *out, int out_dtype,
+                        int B, int C, int H, int W, int copies, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Bit packing of +-1 hash codes and multi-hot labels.
+ * Codes come out of torch.sign(logits) (multi_dino_attention.py:833) as fp32 in {-1,+1};
+ * the reference keeps them as fp32 rows and multiplies (accuracy_calculator.py:183-186).
+ * packed[row][w] bit j  =  src[row][64*w + j] > 0.      words = ceil(nbits / 64).
+ * mode 0 (codes): *bad_flag |= 1 if any value is not exactly +1 or -1 (sign(0)=0, NaN ...)
+ * mode 1 (labels): *bad_flag |= 1 if any value is negative or NaN (then "q.r > 0" is no longer
+ *                  "shares a tag" and label_comparison_fn :31-37 cannot be evaluated on bits).
+ * bad_flag: device int32, caller zero-initialises; may be NULL.
+ * ------------------------------------------------------------------------------------------ */
+int wv_pack_bits(const float *src, int64_t ld_src, uint64_t *packed, int64_t rows, int nbits,
+                 int mode, int32_t *bad_flag, void *stream);
+
+/* Per-bit population counts over the rows (per_bit_balance, accuracy_calculator.py:188-194:
+ * (reference > 0).float().mean(0) = counts / rows).  counts: device uint32[nbits], zeroed here. */
+int wv_bit_counts(const uint64_t *packed, int64_t rows, int nbits, uint32_t *counts, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Hamming distances.  Replaces calc_hamming_dist (accuracy_calculator.py:183-186),
+ * 0.5 * (B - q @ r.T), for +-1 codes, where it is an exact small integer.
+ * dist[qi * ld_dist + n] = popcount(q[qi] ^ db[n]),  uint8 (nbits <= 255).
+ * ------------------------------------------------------------------------------------------ */
+int wv_hamming_dist(const uint64_t *q, const uint64_t *db, uint8_t *dist, int64_t ld_dist, int Q,
+                    int64_t N, int words, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused Hamming distance + ranking: the k nearest database codes of every query in ascending
+ * (distance, database index) order -- the canonical tie-break of torch.argsort(stable=True).
+ * Replaces  hamm = calc_hamming_dist(...); indices = torch.argsort(hamm)[:topk]
+ *   (accuracy_calculator.py:219-223) and get_knn_torch's  q @ r.T + torch.topk(largest=True)
+ *   (get_knn.py:63-66; IP score = nbits - 2 * dist), and faiss IndexFlatIP.search (:35-52).
+ * idx : int32 [Q][k], values = local row + idx_offset (idx_offset = first global row of this
+ *       shard when the database is row-sharded across GPUs).
+ * dist: uint8 [Q][k].        Requires 1 <= k <= N, nbits <= 128.
+ * ------------------------------------------------------------------------------------------ */
+size_t wv_hamming_topk_workspace_bytes(int Q, int64_t N, int words, int k);
+int wv_hamming_topk(const uint64_t *q, const uint64_t *db, int32_t *idx, uint8_t *dist, int Q,
+                    int64_t N, int nbits, int k, int64_t idx_offset, void *workspace,
+                    size_t workspace_bytes, void *stream);
+
+/* Merge of G per-shard top-k lists (gathered with one all-gather) into the global top-k.
+ * Replaces the host-side shard merge inside faiss.index_cpu_to_all_gpus(shards=True)
+ *   (get_knn.py:41-44).  Lists must come from contiguous row shards in rank order, so that
+ * ascending global index inside a distance bucket = (shard, position) order.
+ * idx_in/dist_in: [G][Q][kin];  idx_out/dist_out: [Q][k], k <= G*kin. nbits <= 128. */
+int wv_topk_merge(const int32_t *idx_in, const uint8_t *dist_in, int G, int Q, int kin,
+                  int32_t *idx_out, uint8_t *dist_out, int k, int nbits, void *stream);
+
+/* Ranking from a stored distance matrix row (same order as wv_hamming_topk). */
+int wv_rank_from_dist(const uint8_t *dist_matrix, int64_t ld_dist, int Q, int64_t N, int nbits,
+                      int32_t *idx, uint8_t *dist, int k, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Average precision of each query over its ranked list.
+ * Replaces the per-query body of calculate_maphashing (accuracy_calculator.py:216-229):
+ *   gnd = labels share a tag; tgnd = gnd[indices][:topk]; AP = mean_j(j / rank_j) over hits.
+ * idx: int32 [Q][k] database rows (as written by wv_hamming_topk); entries < 0 are skipped.
+ * qlab [Q][lwords], dblab [N][lwords]: labels packed by wv_pack_bits(mode 1).
+ * ap: float32 [Q] (0 when the query has no hit in its list); nrel: int32 [Q] = hits.
+ * mAP = sum(ap) / Q  (the reference divides by all queries, :231).
+ * ------------------------------------------------------------------------------------------ */
+int wv_map_at_k(const int32_t *idx, int Q, int k, const uint64_t *qlab, const uint64_t *dblab,
+                int lwords, float *ap, int32_t *nrel, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Real-valued k-NN (non-binary embeddings).  Replaces get_knn_torch (get_knn.py:60-71):
+ *   metric 0: scores = q @ r.T,           top-k largest  (hamming / cosine branch)
+ *   metric 1: d = torch.cdist(q, r, p=2), top-k smallest (true L2, not faiss' squared L2)
+ * Ties are broken by ascending database index.  idx int32 [Q][k], val float32 [Q][k].
+ * ------------------------------------------------------------------------------------------ */
+#define WV_METRIC_IP 0
+#define WV_METRIC_L2 1
+size_t wv_knn_float_workspace_bytes(int Q, int64_t N, int D, int k);
+int wv_knn_float(const float *q, const float *db, int Q, int64_t N, int D, int metric, int k,
+                 int32_t *idx, float *val, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Band-attention pooling head + hashing tail (eval mode).
+ * Replaces CrossAttentionBottleneckHeadAdvanced.forward (multi_dino_attention.py:1111-1141;
+ * same core in ...Head :1030-1062, ...Pooled :568-599, ...Decoupled :448-481) and
+ * SharedDinoHashing's tail hash_fc -> BatchNorm1d(eval) -> sign (:829-833).
+ * All weights row-major fp32 exactly as in the module's state_dict.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct wv_head_params {
+    int embed_dim;   /* E (multiple of 32; 384 for ViT-S) */
+    int num_heads;   /* E % num_heads == 0 */
+    int num_queries; /* Nq */
+    int num_tokens;  /* S = 4 band tokens */
+    int pool_mean;   /* 0: concat read-out (Nq*E -> E), 1: mean read-out (E -> E) */
+    const float *q_eff;      /* [Nq][E] effective query tokens (after optional normalise*scale) */
+    const float *in_proj_w;  /* [3E][E] */
+    const float *in_proj_b;  /* [3E] */
+    const float *attn_out_w; /* [E][E] */
+    const float *attn_out_b; /* [E] */
+    const float *norm1_w, *norm1_b; /* [E] */
+    const float *mlp0_w;     /* [4E][E] */
+    const float *mlp0_b;     /* [4E] */
+    const float *mlp2_w;     /* [E][4E] */
+    const float *mlp2_b;     /* [E] */
+    const float *out_w;      /* [E][Nq*E] or [E][E] */
+    const float *out_b;      /* [E] */
+    const float *norm2_w, *norm2_b; /* [E] */
+    float ln_eps;
+} wv_head_params;
+
+size_t wv_band_attn_pool_workspace_bytes(const wv_head_params *p, int B);
+/* feats: [S][B][E] (band-major, the layout cls_tokens.chunk(4) has at :824) -> out [B][E] */
+int wv_band_attn_pool(const wv_head_params *p, const float *feats, int B, float *out,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* logits = fused @ hash_w.T (+ hash_b); BN(eval); codes = sign(logits) as fp32 and bit-packed.
+ * Any of logits_out / codes_out / packed_out may be NULL.  bn_* NULL = no BatchNorm. */
+int wv_hash_tail(const float *fused, int B, int E, const float *hash_w, const float *hash_b,
+                 const float *bn_w, const float *bn_b, const float *bn_mean, const float *bn_var,
+                 float bn_eps, int nbits, float *logits_out, float *codes_out,
+                 uint64_t *packed_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WVHASH_H */

@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.npz.  Run in the BUILD container only (needs /root/reference
+for the attention-head vectors):   python tests/golden/make_golden.py
+
+What each file pins
+* head_golden.npz    -- outputs of the REFERENCE's own fusion-head modules
+  (/root/reference/main/models/multi_dino_attention.py, imported by file path with its
+  sibling hub_utils.py; nothing else of the reference is importable here) on seeded inputs and
+  seeded weights (wvhash.synth.head_state; only the seed and a SHA of the weights are stored).
+  This is the only piece of the hot path whose reference code runs in this image.
+* ranking_golden.npz -- outputs of oracle/ranking.py (stock torch CPU ops, the same calls the
+  reference makes at accuracy_calculator.py:183-231 and get_knn.py:60-71).
+* swt_golden.npz     -- outputs of oracle/swt_oracle.c (PyWavelets is absent: these pin the
+  restatement against regressions and carry the analytic known answers, not pywt output).
+
+Fixtures are data only: inputs and expected outputs.
+"""
+import hashlib
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "image-retrieval-wavelet_amd"))
+sys.dont_write_bytecode = True
+
+from oracle import ranking, swt_np  # noqa: E402
+from wvhash import synth  # noqa: E402
+
+REF = "/root/reference"
+
+
+# --------------------------------------------------------------------------------- head
+def load_reference_heads():
+    pkg = types.ModuleType("refmodels")
+    pkg.__path__ = [os.path.join(REF, "main", "models")]
+    sys.modules["refmodels"] = pkg
+    for name in ("hub_utils", "multi_dino_attention"):
+        spec = importlib.util.spec_from_file_location(
+            f"refmodels.{name}", os.path.join(REF, "main", "models", f"{name}.py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[f"refmodels.{name}"] = mod
+        spec.loader.exec_module(mod)
+    return sys.modules["refmodels.multi_dino_attention"]
+
+
+HEAD_CASES = [
+    # name, fusion type, E, heads, Nq, extra fusion_config, B, seed
+    ("adv_e384_nq4", "cross_attention_advanced", 384, 8, 4, {}, 5, 11),
+    ("adv_e384_nq1", "cross_attention_advanced", 384, 8, 1, {}, 3, 12),
+    ("adv_e384_nq8", "cross_attention_advanced", 384, 8, 8, {}, 2, 13),
+    ("adv_e64_nq4", "cross_attention_advanced", 64, 8, 4, {}, 7, 14),
+    ("base_e384_nq4", "cross_attention_bottleneck", 384, 8, 4, {}, 3, 15),
+    ("pooled_e384_nq4", "cross_attention_pooled", 384, 8, 4, {"query_pool": "mean"}, 3, 16),
+    ("decoupled_e384_nq4", "cross_attention_decoupled", 384, 8, 4,
+     {"query_scale_init": 4.0, "normalize_queries": True}, 3, 17),
+]
+
+
+def make_head_golden():
+    mda = load_reference_heads()
+    out = {}
+    for name, ftype, E, heads, nq, extra, B, seed in HEAD_CASES:
+        cfg = {"type": ftype, "output_dim": E, "num_heads": heads, "dropout": 0.1,
+               "num_queries": nq, "sub_band_dropout_p": 0.0, "ortho_weight": 0.1}
+        cfg.update(extra)
+        head = mda.get_fusion_head(cfg, [E] * 4).eval()
+        pool = "mean" if extra.get("query_pool") == "mean" else "concat"
+        qs = extra.get("query_scale_init")
+        sd = synth.head_state(E, nq, pool, seed, query_scale=qs)
+        missing, unexpected = head.load_state_dict(sd, strict=True), None
+        feats = synth.band_features(B, E, seed + 1000)
+        captured = {}
+        hook = head.attn.register_forward_hook(lambda m, i, o: captured.__setitem__("w", o[1]))
+        with torch.no_grad():
+            y = head([f.clone() for f in feats])
+        hook.remove()
+        out[f"{name}/out"] = y.numpy()
+        out[f"{name}/attn_w"] = captured["w"].numpy()
+        out[f"{name}/meta"] = np.array([E, heads, nq, B, seed, 1 if pool == "mean" else 0,
+                                        1 if ftype.endswith("decoupled") else 0], dtype=np.int64)
+        out[f"{name}/qscale"] = np.array([qs if qs is not None else 0.0], dtype=np.float32)
+        out[f"{name}/sha"] = np.frombuffer(bytes.fromhex(synth.state_sha(sd)), dtype=np.uint8)
+        print(f"head {name}: out {tuple(y.shape)} |y|max {y.abs().max():.3f}")
+    # hashing tail on the first case's output (SharedDinoHashing :829-833 uses plain torch modules)
+    tail = synth.hash_tail_state(384, 64, seed=21)
+    fc = torch.nn.Linear(384, 64, bias=False)
+    bn = torch.nn.BatchNorm1d(64)
+    fc.load_state_dict({"weight": tail["hash_fc.weight"]})
+    bn.load_state_dict({k[3:]: v for k, v in tail.items() if k.startswith("bn.")})
+    fc.eval(), bn.eval()
+    with torch.no_grad():
+        fused = torch.from_numpy(out["adv_e384_nq4/out"])
+        logits = bn(fc(fused))
+    out["tail/logits"] = logits.numpy()
+    out["tail/codes"] = torch.sign(logits).numpy()
+    out["tail/sha"] = np.frombuffer(bytes.fromhex(synth.state_sha(tail)), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "head_golden.npz"), **out)
+
+
+# --------------------------------------------------------------------------------- ranking
+RANK_CASES = [
+    # name, Q, N, nbits, Lc, p, k, structured
+    ("rand_q16_n500_b32", 16, 500, 32, 20, 0.07, 100, False),
+    ("struct_q12_n1000_b64", 12, 1000, 64, 38, 0.10, 300, True),
+    ("struct_q8_n777_b128", 8, 777, 128, 80, 0.036, 777, True),
+    ("rand_q5_n64_b16", 5, 64, 16, 20, 0.07, 10, False),
+]
+
+
+def make_ranking_golden():
+    out = {}
+    for name, Q, N, B, Lc, p, k, structured in RANK_CASES:
+        seed = int(hashlib.sha256(name.encode()).hexdigest()[:6], 16)
+        ql = ranking.make_labels(Q, Lc, p, seed)
+        rl = ranking.make_labels(N, Lc, p, seed + 1)
+        if structured:
+            q = ranking.make_structured_codes(ql, B, seed + 2, seed + 3)
+            r = ranking.make_structured_codes(rl, B, seed + 2, seed + 4)
+        else:
+            q, r = ranking.make_codes(Q, N, B, seed)
+        d = torch.cat([ranking.calc_hamming_dist(q[i:i + 1], r) for i in range(Q)])
+        idx, dk = ranking.hamming_topk_stable(q, r, k)
+        m_ref, ap_ref = ranking.calculate_maphashing(q, ql, r, rl, k, stable=False, return_per_query=True)
+        m_st, ap_st = ranking.calculate_maphashing(q, ql, r, rl, k, stable=True, return_per_query=True)
+        knn_d, knn_i = ranking.get_knn_torch(r, q, min(k, 50), "hamming")
+        out.update({
+            f"{name}/q": q.numpy().astype(np.int8), f"{name}/r": r.numpy().astype(np.int8),
+            f"{name}/ql": ql.numpy().astype(np.uint8), f"{name}/rl": rl.numpy().astype(np.uint8),
+            f"{name}/k": np.array([k]),
+            f"{name}/dist": d.numpy().astype(np.float32),
+            f"{name}/topk_idx": idx.numpy().astype(np.int32),
+            f"{name}/topk_dist": dk.numpy().astype(np.uint8),
+            f"{name}/ap_stable": np.array(ap_st, dtype=np.float64),
+            f"{name}/ap_ref": np.array(ap_ref, dtype=np.float64),
+            f"{name}/map_stable": np.array([m_st]), f"{name}/map_ref": np.array([m_ref]),
+            f"{name}/bit_balance": np.array([ranking.calculate_bit_balance(r),
+                                             ranking.calculate_worst_bit_balance(r)]),
+            f"{name}/knn_ip": knn_d.numpy(), f"{name}/knn_idx_ref": knn_i.numpy().astype(np.int32),
+        })
+        print(f"rank {name}: mAP stable {m_st:.6f} ref(unstable) {m_ref:.6f}")
+    # float embeddings for the l2 / cosine k-NN entry points (get_knn.py:60-71)
+    g = torch.Generator().manual_seed(77)
+    qe = torch.randn(9, 48, generator=g)
+    re_ = torch.randn(301, 48, generator=g)
+    for metric in ("l2", "cosine"):
+        a, b = (torch.nn.functional.normalize(qe), torch.nn.functional.normalize(re_)) \
+            if metric == "cosine" else (qe, re_)
+        dd, ii = ranking.get_knn_torch(b, a, 20, metric)
+        out[f"float_{metric}/q"] = a.numpy()
+        out[f"float_{metric}/r"] = b.numpy()
+        out[f"float_{metric}/dist"] = dd.numpy()
+        out[f"float_{metric}/idx"] = ii.numpy().astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, "ranking_golden.npz"), **out)
+
+
+# --------------------------------------------------------------------------------- SWT
+SWT_CASES = [
+    ("haar_l1_32x32", "haar", 1, 32, 32, "noise"),
+    ("db2_l3_32x48", "db2", 3, 32, 48, "natural"),
+    ("db4_l1_16x16", "db4", 1, 16, 16, "noise"),
+    ("bior44_l1_24x40", "bior4.4", 1, 24, 40, "natural"),
+    ("haar_l2_8x8", "haar", 2, 8, 8, "noise"),
+    ("db2_l2_64x64", "db2", 2, 64, 64, "natural"),
+]
+
+
+def make_swt_golden():
+    out = {}
+    for i, (name, wl, lev, H, W, kind) in enumerate(SWT_CASES):
+        gen = synth.noise_images if kind == "noise" else synth.natural_images
+        img = gen(2, H, W, seed=100 + i)
+        y = swt_np.c_transform_batch(img, wl, lev)
+        out[f"{name}/img"] = img
+        out[f"{name}/out"] = y
+        out[f"{name}/meta"] = np.array([lev, H, W])
+        out[f"{name}/wavelet"] = np.frombuffer(wl.encode(), dtype=np.uint8)
+        print(f"swt {name}: LL [{y[:, :, 0].min():.4f}, {y[:, :, 0].max():.4f}] "
+              f"detail mean {y[:, :, 1:].mean():+.2e}")
+    # the BASELINE c1 shape: one 224x224 image, db2 level 3 -> SHA-256 + sparse samples only
+    img = synth.natural_images(1, 224, 224, seed=1234)
+    y = swt_np.c_transform_batch(img, "db2", 3)
+    out["db2_l3_224/sha"] = np.frombuffer(hashlib.sha256(y.tobytes()).digest(), dtype=np.uint8)
+    out["db2_l3_224/samples"] = y.reshape(-1)[::9973].copy()
+    np.savez_compressed(os.path.join(HERE, "swt_golden.npz"), **out)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(1)
+    make_swt_golden()
+    make_ranking_golden()
+    make_head_golden()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -1,0 +1,111 @@
+"""Pins oracle/ranking.py (CPU only): committed golden vectors + the behavioural known answers of
+/root/reference/studies/measure_random_baseline.py (constant codes -> mAP = relevance-driven
+floor; random codes ~ relevance density)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ranking
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(f"{golden_dir}/ranking_golden.npz")
+
+
+def case_names(g):
+    return sorted({k.split("/")[0] for k in g.files if k.endswith("/topk_idx")})
+
+
+def load_case(g, n):
+    t = lambda k, dt=torch.float32: torch.from_numpy(g[f"{n}/{k}"].astype(np.float32)).to(dt)
+    return t("q"), t("r"), t("ql"), t("rl"), int(g[f"{n}/k"][0])
+
+
+def test_golden_distances_topk_and_map(gold):
+    names = case_names(gold)
+    assert len(names) == 4
+    for n in names:
+        q, r, ql, rl, k = load_case(gold, n)
+        d = ranking.calc_hamming_dist(q, r)
+        np.testing.assert_array_equal(d.numpy(), gold[f"{n}/dist"])
+        idx, dk = ranking.hamming_topk_stable(q, r, k)
+        np.testing.assert_array_equal(idx.numpy(), gold[f"{n}/topk_idx"])
+        np.testing.assert_array_equal(dk.numpy(), gold[f"{n}/topk_dist"])
+        m, ap = ranking.calculate_maphashing(q, ql, r, rl, k, stable=True, return_per_query=True)
+        np.testing.assert_allclose(ap, gold[f"{n}/ap_stable"], rtol=0, atol=0)
+        assert m == gold[f"{n}/map_stable"][0]
+        bb = [ranking.calculate_bit_balance(r), ranking.calculate_worst_bit_balance(r)]
+        np.testing.assert_array_equal(bb, gold[f"{n}/bit_balance"])
+
+
+def test_hamming_formula_is_exact_integer_popcount(gold):
+    for n in case_names(gold):
+        q, r, *_ = load_case(gold, n)
+        d = ranking.calc_hamming_dist(q, r)
+        brute = ((q[:, None, :] != r[None, :, :]).sum(-1)).float()
+        assert torch.equal(d, brute)
+
+
+def test_unstable_reference_order_differs_only_inside_ties(gold):
+    """argsort(stable=False) (the reference's literal call) vs the canonical order: same sorted
+    distances, same index set in every complete bucket."""
+    for n in case_names(gold):
+        q, r, ql, rl, k = load_case(gold, n)
+        d = ranking.hamming_matrix_u8(q, r)
+        idx_s, dk_s = ranking.hamming_topk_stable(q, r, k)
+        for i in range(q.shape[0]):
+            un = torch.argsort(d[i].float())[:k]
+            assert torch.equal(d[i][un], dk_s[i])
+            assert ranking.bucket_sets(un, d[i][un]) == ranking.bucket_sets(idx_s[i], dk_s[i])
+        # the reference-order mAP stored in the fixture stays within tie noise of the canonical one
+        assert abs(gold[f"{n}/map_ref"][0] - gold[f"{n}/map_stable"][0]) < 0.05
+
+
+def test_constant_codes_give_relevance_floor():
+    """measure_random_baseline.py:110-115: every code identical -> ranking = database order."""
+    ql = ranking.make_labels(20, 38, 0.1, 1)
+    rl = ranking.make_labels(400, 38, 0.1, 2)
+    q, r = torch.ones(20, 64), torch.ones(400, 64)
+    m = ranking.calculate_maphashing(q, ql, r, rl, 100, stable=True)
+    rel = ranking.label_comparison_fn(ql, rl).float()[:, :100]
+    expect = 0.0
+    for i in range(20):
+        hits = torch.where(rel[i] == 1)[0].float() + 1
+        if len(hits):
+            expect += (torch.arange(1, len(hits) + 1).float() / hits).mean().item()
+    assert abs(m - expect / 20) < 1e-12
+
+
+def test_zero_hit_queries_count_as_zero_and_topk_none_means_all():
+    q, r = ranking.make_codes(3, 50, 16, 3)
+    ql = torch.zeros(3, 5); ql[:, 0] = 1
+    rl = torch.zeros(50, 5); rl[:, 1] = 1
+    assert ranking.calculate_maphashing(q, ql, r, rl, 10) == 0.0
+    rl[7, 0] = 1
+    a = ranking.calculate_maphashing(q, ql, r, rl, None, stable=True)
+    b = ranking.calculate_maphashing(q, ql, r, rl, 50, stable=True)
+    assert a == b > 0
+
+
+def test_label_comparison_branches():
+    a = torch.tensor([[1., 0, 1], [0, 1, 0]])
+    b = torch.tensor([[0., 0, 1], [0, 0, 0], [1, 1, 0]])
+    assert ranking.label_comparison_fn(a, b).tolist() == [[True, False, True], [False, False, True]]
+    ids_q, ids_r = torch.tensor([3, 5]), torch.tensor([5, 3, 3])
+    assert ranking.label_comparison_fn(ids_q, ids_r).tolist() == [[False, True, True], [True, False, False]]
+    knn = b[torch.tensor([[0, 2], [1, 2]])]            # [Q, k, Lc] vs [Q, 1, Lc]
+    assert ranking.label_comparison_fn(a[:, None], knn).tolist() == [[True, True], [False, True]]
+
+
+def test_get_knn_shapes_and_same_source(gold):
+    q, r, *_ = load_case(gold, "rand_q16_n500_b32")
+    idx, dist = ranking.get_knn(r, q, 10, False, distance_metric="hamming")
+    assert idx.shape == (16, 10) and dist.shape == (16, 10) and idx.dtype == torch.int64
+    np.testing.assert_array_equal(dist.numpy(), gold["rand_q16_n500_b32/knn_ip"][:, :10])
+    idx2, dist2 = ranking.get_knn(r, r[:4], 5, True, distance_metric="hamming")
+    assert idx2.shape == (4, 5) and (dist2 <= 32).all()
+    for m in ("l2", "cosine"):
+        d, i = ranking.get_knn_torch(torch.from_numpy(gold[f"float_{m}/r"]), torch.from_numpy(gold[f"float_{m}/q"]), 20, m)
+        np.testing.assert_array_equal(i.numpy(), gold[f"float_{m}/idx"])
+        np.testing.assert_allclose(d.numpy(), gold[f"float_{m}/dist"], rtol=1e-6)
