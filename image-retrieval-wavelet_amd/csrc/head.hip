@@ -1,12 +1,336 @@
-// placeholder until the real kernels land later this round
+// Band-attention pooling head + hashing tail (eval mode) for gfx950.
+//
+// Reference: CrossAttentionBottleneckHeadAdvanced.forward
+// (/root/reference/main/models/multi_dino_attention.py:1111-1141): learned query tokens attend
+// over the 4 band tokens through nn.MultiheadAttention, then LN, a GELU MLP, a read-out Linear
+// and LN; SharedDinoHashing's tail (:829-833): hash_fc -> BatchNorm1d(eval) -> sign.
+//
+// Every dense contraction (K/V in_proj, attention out_proj, both MLP layers, the read-out) runs
+// on the matrix cores with v_mfma_f32_32x32x2_f32 -- fp32 in, fp32 accumulate, bit-for-bit an
+// fmaf chain -- so the result stays within fp32 rounding of the reference's fp32 ATen path
+// instead of trading precision for bf16 MFMA rate.  The 4-token softmax / context step is a small
+// VALU kernel (QK^T is Nq x 4 per head).  The batch-invariant query projection is done once per
+// call.  Stages are separate launches writing to a caller workspace.
 #include "common.hpp"
-extern "C" size_t wv_band_attn_pool_workspace_bytes(const wv_head_params *, int) { return 0; }
-extern "C" int wv_band_attn_pool(const wv_head_params *, const float *, int, float *, void *, size_t, void *)
+
+namespace wv {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_ADD_ROW = 2, EPI_ADD_BCAST = 3 };
+
+// C[M][N] = epi(A[M][K] . W[N][K]^T + bias[N])
+//   EPI_ADD_ROW   : + R[m][n]                    (residual of the same shape)
+//   EPI_ADD_BCAST : + R[(m % rmod)][n]           (query tokens broadcast over the batch)
+// Wave tile = (32*TM) x (32*TN); workgroup = 2 x 2 waves.  Same operand scheme as k_scores
+// (knn_float.hip): lane l feeds row l&31, lane half h covers k in [8c+4h, 8c+4h+4).
+template <int TM, int TN, int EPI>
+__global__ __launch_bounds__(256) void k_gemm_nt(const float *__restrict__ A, const float *__restrict__ W,
+                                                 const float *__restrict__ bias,
+                                                 const float *__restrict__ R, int rmod,
+                                                 float *__restrict__ C, int M, int N, int K)
 {
-    WV_FAIL(WV_ENOTSUP, "band_attn_pool: not built yet");
+    const int lane = lane_id(), wv = wave_id();
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t i0 = (int64_t)blockIdx.y * (64 * TM) + (wv >> 1) * (32 * TM);
+    const int64_t j0 = (int64_t)blockIdx.x * (64 * TN) + (wv & 1) * (32 * TN);
+    if (i0 >= M || j0 >= N) return;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    const float *arow[TM], *brow[TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) arow[a] = A + min(i0 + a * 32 + r, (int64_t)M - 1) * K;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) brow[b] = W + min(j0 + b * 32 + r, (int64_t)N - 1) * K;
+
+    for (int k = 0; k < K; k += 8) {  // K % 8 == 0 (checked on the host)
+        float4 av[TM], bv[TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) av[a] = *reinterpret_cast<const float4 *>(arow[a] + k + 4 * h);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bv[b] = *reinterpret_cast<const float4 *>(brow[b] + k + 4 * h);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].x, bv[b].x, acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].y, bv[b].y, acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].z, bv[b].z, acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].w, bv[b].w, acc[a][b], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int64_t col = j0 + b * 32 + r;
+            if (col >= N) continue;
+            const float bs = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t row = i0 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row >= M) continue;
+                float v = acc[a][b][e] + bs;
+                if (EPI == EPI_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                if (EPI == EPI_ADD_ROW) v += R[row * N + col];
+                if (EPI == EPI_ADD_BCAST) v += R[(row % rmod) * N + col];
+                C[row * N + col] = v;
+            }
+        }
 }
-extern "C" int wv_hash_tail(const float *, int, int, const float *, const float *, const float *, const float *,
-                            const float *, const float *, float, int, float *, float *, uint64_t *, void *)
+
+// Softmax over the S band tokens and the context vectors, one workgroup per sample.
+//   Qp  [Nq][E]        projected queries (batch-invariant)
+//   KV  [S*B][2E]      row s*B + b = (K | V) of token s of sample b
+//   ctx [B*Nq][E]
+__global__ __launch_bounds__(256) void k_attn_core(const float *__restrict__ Qp,
+                                                   const float *__restrict__ KV,
+                                                   float *__restrict__ ctx, int B, int E, int heads,
+                                                   int Nq, int S)
 {
-    WV_FAIL(WV_ENOTSUP, "hash_tail: not built yet");
+    extern __shared__ float sm[];  // P[Nq][heads][S]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int hd = E / heads;
+    const float scale = 1.0f / sqrtf((float)hd);
+    const int ndots = Nq * heads * S;
+    for (int t = tid; t < ndots; t += blockDim.x) {
+        const int s = t % S, hh = (t / S) % heads, i = t / (S * heads);
+        const float *qv = Qp + (size_t)i * E + hh * hd;
+        const float *kv = KV + ((size_t)s * B + b) * 2 * E + hh * hd;
+        float acc = 0.f;
+        for (int d = 0; d < hd; ++d) acc = fmaf(qv[d], kv[d], acc);
+        sm[t] = acc * scale;
+    }
+    __syncthreads();
+    for (int t = tid; t < Nq * heads; t += blockDim.x) {
+        float *p = sm + (size_t)t * S;
+        float mx = p[0];
+        for (int s = 1; s < S; ++s) mx = fmaxf(mx, p[s]);
+        float sum = 0.f;
+        for (int s = 0; s < S; ++s) {
+            p[s] = expf(p[s] - mx);
+            sum += p[s];
+        }
+        for (int s = 0; s < S; ++s) p[s] = p[s] / sum;
+    }
+    __syncthreads();
+    for (int t = tid; t < Nq * E; t += blockDim.x) {
+        const int e = t % E, i = t / E, hh = e / hd;
+        const float *p = sm + ((size_t)i * heads + hh) * S;
+        float acc = 0.f;
+        for (int s = 0; s < S; ++s) acc = fmaf(p[s], KV[((size_t)s * B + b) * 2 * E + E + e], acc);
+        ctx[((size_t)b * Nq + i) * E + e] = acc;
+    }
+}
+
+// y = LayerNorm(x) over rows of length E (one wave per row), optional mean over groups of `pool`
+// consecutive rows afterwards is handled by k_mean_rows.
+__global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, const float *__restrict__ w,
+                                                   const float *__restrict__ bvec, float *__restrict__ y,
+                                                   int64_t rows, int E, float eps)
+{
+    const int lane = lane_id();
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave_id();
+    if (row >= rows) return;
+    const float *xr = x + row * E;
+    float s = 0.f;
+    for (int e = lane; e < E; e += 64) s += xr[e];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+    const float mean = s / (float)E;
+    float v = 0.f;
+    for (int e = lane; e < E; e += 64) {
+        const float dlt = xr[e] - mean;
+        v = fmaf(dlt, dlt, v);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    const float rstd = 1.0f / sqrtf(v / (float)E + eps);
+    for (int e = lane; e < E; e += 64) y[row * E + e] = (xr[e] - mean) * rstd * w[e] + bvec[e];
+}
+
+__global__ void k_mean_rows(const float *__restrict__ x, float *__restrict__ y, int64_t groups, int n, int E)
+{
+    const int64_t total = groups * E;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g = i / E;
+        const int e = (int)(i - g * E);
+        float s = 0.f;
+        for (int j = 0; j < n; ++j) s += x[(g * n + j) * E + e];
+        y[i] = s / (float)n;
+    }
+}
+
+// logits = fused @ Wh^T (+bh); BatchNorm1d eval; codes = sign(logits); bit-pack (bit = logit > 0)
+__global__ __launch_bounds__(256) void k_hash_tail(const float *__restrict__ fused, int B, int E,
+                                                   const float *__restrict__ hw, const float *__restrict__ hb,
+                                                   const float *__restrict__ bn_w, const float *__restrict__ bn_b,
+                                                   const float *__restrict__ bn_mean,
+                                                   const float *__restrict__ bn_var, float eps, int nbits,
+                                                   float *__restrict__ logits_out,
+                                                   float *__restrict__ codes_out,
+                                                   uint64_t *__restrict__ packed_out)
+{
+    extern __shared__ float xrow[];  // E floats
+    const int b = blockIdx.x, tid = threadIdx.x, lane = lane_id();
+    for (int e = tid; e < E; e += blockDim.x) xrow[e] = fused[(size_t)b * E + e];
+    __syncthreads();
+    const int words = (nbits + 63) / 64;
+    for (int j0 = 0; j0 < words * 64; j0 += blockDim.x) {
+        const int j = j0 + tid;
+        float v = 0.f;
+        const bool valid = j < nbits;
+        if (valid) {
+            const float4 *wr = reinterpret_cast<const float4 *>(hw + (size_t)j * E);
+            float acc = 0.f;
+            for (int e4 = 0; e4 < E / 4; ++e4) {
+                const float4 w4 = wr[e4];
+                acc = fmaf(w4.x, xrow[4 * e4 + 0], acc);
+                acc = fmaf(w4.y, xrow[4 * e4 + 1], acc);
+                acc = fmaf(w4.z, xrow[4 * e4 + 2], acc);
+                acc = fmaf(w4.w, xrow[4 * e4 + 3], acc);
+            }
+            v = acc + (hb ? hb[j] : 0.f);
+            if (bn_w) v = (v - bn_mean[j]) / sqrtf(bn_var[j] + eps) * bn_w[j] + bn_b[j];
+            if (logits_out) logits_out[(size_t)b * nbits + j] = v;
+            if (codes_out) codes_out[(size_t)b * nbits + j] = v > 0.f ? 1.f : (v < 0.f ? -1.f : (v == 0.f ? 0.f : v));
+        }
+        const uint64_t word = __ballot(valid && v > 0.f);
+        if (packed_out && lane == 0 && j < words * 64) packed_out[(size_t)b * words + j / 64] = word;
+    }
+}
+
+template <int EPI>
+static void launch_gemm(const float *A, const float *W, const float *bias, const float *R, int rmod,
+                        float *C, int M, int N, int K, hipStream_t st)
+{
+    // big tile when it still yields >= 256 workgroups, else the small one
+    const int64_t big = ceil_div(M, 128) * ceil_div(N, 128);
+    if (big >= 256) {
+        dim3 grid((unsigned)ceil_div(N, 128), (unsigned)ceil_div(M, 128));
+        hipLaunchKernelGGL((k_gemm_nt<2, 2, EPI>), grid, dim3(256), 0, st, A, W, bias, R, rmod, C, M, N, K);
+    } else {
+        dim3 grid((unsigned)ceil_div(N, 64), (unsigned)ceil_div(M, 64));
+        hipLaunchKernelGGL((k_gemm_nt<1, 1, EPI>), grid, dim3(256), 0, st, A, W, bias, R, rmod, C, M, N, K);
+    }
+}
+
+struct HeadWs {
+    float *Qp, *KV, *ctx, *x1, *x1n, *hid, *x2, *pooled, *pre;
+    size_t bytes;
+};
+
+static HeadWs carve(const wv_head_params *p, int B, void *base)
+{
+    const size_t E = p->embed_dim, Nq = p->num_queries, S = p->num_tokens;
+    const size_t rows = (size_t)B * Nq;
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        float *r = base ? (float *)((char *)base + off) : nullptr;
+        off += align_up((int64_t)(n * sizeof(float)), 256);
+        return r;
+    };
+    HeadWs w;
+    w.Qp = take(Nq * E);
+    w.KV = take(S * B * 2 * E);
+    w.ctx = take(rows * E);
+    w.x1 = take(rows * E);
+    w.x1n = take(rows * E);
+    w.hid = take(rows * 4 * E);
+    w.x2 = take(rows * E);
+    w.pooled = take((size_t)B * E);
+    w.pre = take((size_t)B * E);
+    w.bytes = off;
+    return w;
+}
+
+}  // namespace wv
+
+using namespace wv;
+
+static int check_head(const wv_head_params *p, int B)
+{
+    WV_REQUIRE(p, "band_attn_pool: null params");
+    WV_REQUIRE(B >= 0, "band_attn_pool: B=%d", B);
+    WV_REQUIRE(p->embed_dim >= 8 && p->embed_dim % 8 == 0, "band_attn_pool: embed_dim=%d must be a multiple of 8",
+               p->embed_dim);
+    WV_REQUIRE(p->num_heads >= 1 && p->embed_dim % p->num_heads == 0,
+               "band_attn_pool: embed_dim %d not divisible by num_heads %d", p->embed_dim, p->num_heads);
+    WV_REQUIRE(p->num_queries >= 1 && p->num_queries <= 64, "band_attn_pool: num_queries=%d", p->num_queries);
+    WV_REQUIRE(p->num_tokens >= 1 && p->num_tokens <= 64, "band_attn_pool: num_tokens=%d", p->num_tokens);
+    WV_REQUIRE(p->q_eff && p->in_proj_w && p->in_proj_b && p->attn_out_w && p->attn_out_b && p->norm1_w &&
+                   p->norm1_b && p->mlp0_w && p->mlp0_b && p->mlp2_w && p->mlp2_b && p->out_w && p->out_b &&
+                   p->norm2_w && p->norm2_b,
+               "band_attn_pool: null weight pointer");
+    return WV_OK;
+}
+
+extern "C" size_t wv_band_attn_pool_workspace_bytes(const wv_head_params *p, int B)
+{
+    if (!p || B <= 0) return 0;
+    return carve(p, B, nullptr).bytes;
+}
+
+extern "C" int wv_band_attn_pool(const wv_head_params *p, const float *feats, int B, float *out,
+                                 void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = check_head(p, B);
+    if (rc) return rc;
+    WV_REQUIRE(feats && out, "band_attn_pool: null buffer");
+    if (B == 0) return WV_OK;
+    const size_t need = carve(p, B, nullptr).bytes;
+    if (!workspace || workspace_bytes < need)
+        WV_FAIL(WV_ENOMEM, "band_attn_pool: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    const int E = p->embed_dim, Nq = p->num_queries, S = p->num_tokens, rows = B * Nq;
+    HeadWs w = carve(p, B, workspace);
+
+    // Q projection (batch-invariant): Qp = q_eff @ Wq^T + bq
+    launch_gemm<EPI_NONE>(p->q_eff, p->in_proj_w, p->in_proj_b, nullptr, 1, w.Qp, Nq, E, E, st);
+    // K | V projection of all S*B tokens: rows E..3E of in_proj_weight
+    launch_gemm<EPI_NONE>(feats, p->in_proj_w + (size_t)E * E, p->in_proj_b + E, nullptr, 1, w.KV, S * B, 2 * E, E, st);
+    const size_t sm = (size_t)Nq * p->num_heads * S * sizeof(float);
+    hipLaunchKernelGGL(k_attn_core, dim3(B), dim3(256), sm, st, w.Qp, w.KV, w.ctx, B, E, p->num_heads, Nq, S);
+    // x1 = q_eff + ctx @ Wo^T + bo ; x1n = LN1(x1)
+    launch_gemm<EPI_ADD_BCAST>(w.ctx, p->attn_out_w, p->attn_out_b, p->q_eff, Nq, w.x1, rows, E, E, st);
+    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, w.x1, p->norm1_w,
+                       p->norm1_b, w.x1n, (int64_t)rows, E, p->ln_eps);
+    // x2 = x1n + GELU(x1n @ W0^T + b0) @ W2^T + b2
+    launch_gemm<EPI_GELU>(w.x1n, p->mlp0_w, p->mlp0_b, nullptr, 1, w.hid, rows, 4 * E, E, st);
+    launch_gemm<EPI_ADD_ROW>(w.hid, p->mlp2_w, p->mlp2_b, w.x1n, 1, w.x2, rows, E, 4 * E, st);
+    // read-out: concat (a [B][Nq*E] view of x2) or mean over the queries, then Linear + LN2
+    if (p->pool_mean) {
+        hipLaunchKernelGGL(k_mean_rows, dim3((unsigned)std::min<int64_t>(ceil_div((int64_t)B * E, 256), 4096)),
+                           dim3(256), 0, st, w.x2, w.pooled, (int64_t)B, Nq, E);
+        launch_gemm<EPI_NONE>(w.pooled, p->out_w, p->out_b, nullptr, 1, w.pre, B, E, E, st);
+    } else {
+        launch_gemm<EPI_NONE>(w.x2, p->out_w, p->out_b, nullptr, 1, w.pre, B, E, Nq * E, st);
+    }
+    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, st, w.pre, p->norm2_w,
+                       p->norm2_b, out, (int64_t)B, E, p->ln_eps);
+    WV_CHECK_LAUNCH("band_attn_pool");
+    return WV_OK;
+}
+
+extern "C" int wv_hash_tail(const float *fused, int B, int E, const float *hash_w, const float *hash_b,
+                            const float *bn_w, const float *bn_b, const float *bn_mean,
+                            const float *bn_var, float bn_eps, int nbits, float *logits_out,
+                            float *codes_out, uint64_t *packed_out, void *stream)
+{
+    WV_REQUIRE(fused && hash_w, "hash_tail: null buffer");
+    WV_REQUIRE(B >= 0 && E >= 4 && E % 4 == 0 && nbits >= 1, "hash_tail: bad shape B=%d E=%d nbits=%d", B, E, nbits);
+    WV_REQUIRE(!bn_w || (bn_b && bn_mean && bn_var), "hash_tail: incomplete BatchNorm parameters");
+    WV_REQUIRE(E * sizeof(float) <= 48 * 1024, "hash_tail: E=%d too large", E);
+    if (B == 0) return WV_OK;
+    hipLaunchKernelGGL(k_hash_tail, dim3(B), dim3(256), E * sizeof(float), (hipStream_t)stream, fused, B, E,
+                       hash_w, hash_b, bn_w, bn_b, bn_mean, bn_var, bn_eps, nbits, logits_out, codes_out,
+                       packed_out);
+    WV_CHECK_LAUNCH("k_hash_tail");
+    return WV_OK;
 }

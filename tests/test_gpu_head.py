@@ -1,0 +1,133 @@
+"""GPU parity of the HIP/MFMA band-attention head and the hashing tail against the outputs of the
+REFERENCE's own modules (tests/golden/head_golden.npz) and against oracle/head_torch.py.
+
+Tolerance: every contraction is fp32 (v_mfma_f32_32x32x2_f32 = fmaf chain); only the summation
+order differs from ATen's blocked fp32 GEMM.  Outputs are LayerNorm'ed (|y| ~ 3): atol 5e-5.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import head_torch
+from wvhash import synth
+from wvhash.models import get_fusion_head, hash_tail, SharedDinoHashing, MultiDinoHashing
+from wvhash.models.vit import tiny_vit
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 5e-5
+TYPES = {"adv": "cross_attention_advanced", "base": "cross_attention_bottleneck",
+         "pooled": "cross_attention_pooled", "decoupled": "cross_attention_decoupled"}
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(f"{golden_dir}/head_golden.npz")
+
+
+def build(n, gold):
+    E, heads, nq, B, seed, mean, dec = gold[n + "/meta"].tolist()
+    cfg = {"type": TYPES[n.split("_")[0]], "output_dim": E, "num_heads": heads, "num_queries": nq,
+           "sub_band_dropout_p": 0.0, "ortho_weight": 0.1}
+    if mean:
+        cfg["query_pool"] = "mean"
+    qs = float(gold[n + "/qscale"][0])
+    if dec:
+        cfg["query_scale_init"] = qs
+    head = get_fusion_head(cfg, [E] * 4)
+    sd = synth.head_state(E, nq, "mean" if mean else "concat", seed, query_scale=qs if dec else None)
+    head.load_state_dict(sd)
+    return head.cuda().eval(), synth.band_features(B, E, seed + 1000), sd
+
+
+def test_heads_match_reference_module_outputs(gold):
+    names = sorted({k.split("/")[0] for k in gold.files if k.endswith("/meta")})
+    assert len(names) == 7
+    for n in names:
+        head, feats, _ = build(n, gold)
+        with torch.no_grad():
+            y = head([f.cuda() for f in feats])
+        assert y.shape == gold[n + "/out"].shape
+        assert np.abs(y.cpu().numpy() - gold[n + "/out"]).max() < ATOL, n
+        assert float(head.last_ortho_loss) == 0.0
+
+
+@pytest.mark.parametrize("B", [1, 63, 256, 2048])
+def test_batch_sizes_against_oracle(B):
+    sd = synth.head_state(384, 4, "concat", seed=5)
+    head = get_fusion_head({"type": "cross_attention_advanced", "output_dim": 384, "num_queries": 4}, [384] * 4)
+    head.load_state_dict(sd)
+    head = head.cuda().eval()
+    feats = synth.band_features(B, 384, seed=B)
+    with torch.no_grad():
+        y = head([f.cuda() for f in feats])
+        y2 = head([f.cuda() for f in feats])
+    assert torch.equal(y, y2)                                   # deterministic
+    ref = head_torch.band_attn_pool(feats, sd, 8)
+    assert (y.cpu() - ref).abs().max().item() < ATOL
+    ref64 = head_torch.band_attn_pool(feats[:1] if False else feats, sd, 8, dtype=torch.float64)
+    assert (y.cpu().double() - ref64).abs().max().item() < ATOL
+
+
+def test_hip_path_equals_stock_torch_forward_of_same_module():
+    head = get_fusion_head({"type": "cross_attention_advanced", "output_dim": 384, "num_queries": 4}, [384] * 4)
+    head.load_state_dict(synth.head_state(384, 4, "concat", seed=9))
+    head = head.cuda().eval()
+    feats = [f.cuda() for f in synth.band_features(32, 384, seed=10)]
+    with torch.no_grad():
+        y = head(feats)
+    grad_feats = [f.clone().requires_grad_(True) for f in feats]   # autograd needed -> torch path
+    y_t = head(grad_feats)
+    assert y_t.requires_grad and (y - y_t.detach()).abs().max().item() < ATOL
+
+
+def test_hash_tail_against_reference_and_packing(gold):
+    tail = synth.hash_tail_state(384, 64, seed=21)
+    fc = torch.nn.Linear(384, 64, bias=False)
+    bn = torch.nn.BatchNorm1d(64)
+    fc.load_state_dict({"weight": tail["hash_fc.weight"]})
+    bn.load_state_dict({k[3:]: v for k, v in tail.items() if k.startswith("bn.")})
+    fc, bn = fc.cuda().eval(), bn.cuda().eval()
+    fused = torch.from_numpy(gold["adv_e384_nq4/out"]).cuda()
+    out = hash_tail(fused, fc, bn, want=("logits", "codes", "packed"))
+    np.testing.assert_allclose(out["logits"].cpu().numpy(), gold["tail/logits"], atol=5e-6)
+    far = np.abs(gold["tail/logits"]) > 1e-4
+    assert np.array_equal(out["codes"].cpu().numpy()[far], gold["tail/codes"][far])
+    from wvhash.engine import hamming as H
+    assert torch.equal(out["packed"], H.pack_codes(out["codes"]))
+    # 128-bit codes, bias and no BN
+    fc2 = torch.nn.Linear(384, 128, bias=True).cuda().eval()
+    big = torch.randn(300, 384, device="cuda")
+    o2 = hash_tail(big, fc2, torch.nn.Identity(), want=("logits", "codes", "packed"))
+    ref = torch.nn.functional.linear(big.cpu(), fc2.weight.cpu(), fc2.bias.cpu())
+    assert (o2["logits"].cpu() - ref).abs().max().item() < 1e-5
+    assert torch.equal(o2["packed"], H.pack_codes(o2["codes"]))
+
+
+def test_model_classes_end_to_end_with_stub_backbone():
+    torch.manual_seed(0)
+    fusion = {"type": "cross_attention_advanced", "output_dim": 384, "num_heads": 8, "num_queries": 4,
+              "sub_band_dropout_p": 0, "ortho_weight": 0.1, "dropout": 0.1}
+    net = SharedDinoHashing({"name": "dinov2_vits14", "frozen": True}, fusion, {"nbits": 64},
+                            backbone=tiny_vit(), modelhooks={"name": "x"}, with_autocast=True).cuda().eval()
+    net.set_wavelet(level=1, wavelet="haar")
+    img = torch.from_numpy(synth.natural_images(4, 224, 224, seed=3)).permute(0, 3, 1, 2).contiguous().cuda()
+    from wvhash.transforms import swt2d
+    with torch.no_grad():
+        codes_raw = net(img)                                     # 4-D raw batch -> SWT on device
+        codes_5d = net(swt2d(img, "haar", 1))                    # reference-style 5-D input
+        packed = net.encode_packed(img)
+    assert tuple(codes_raw.shape) == (4, 64) and torch.equal(codes_raw, codes_5d)
+    assert set(codes_raw.unique().tolist()) <= {-1.0, 0.0, 1.0}
+    from wvhash.engine import hamming as H
+    assert torch.equal(packed, H.pack_codes(codes_raw, check=False))
+    # stock-torch evaluation of the same tail agrees except at |logit| ~ 0
+    with torch.no_grad():
+        fused = net.fused_embedding(img)
+        logits = net.bn(net.hash_fc(fused))
+    far = logits.abs() > 1e-4
+    assert torch.equal(torch.sign(logits)[far], codes_raw[far])
+    multi = MultiDinoHashing([{"name": "dinov2_vits14"}] * 4, fusion, {"nbits": 32},
+                             backbones=[tiny_vit() for _ in range(4)]).cuda().eval()
+    with torch.no_grad():
+        assert tuple(multi(swt2d(img, "haar", 1)).shape) == (4, 32)

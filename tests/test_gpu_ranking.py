@@ -177,3 +177,59 @@ def test_full_size_properties_c1():
     # oracle on a slice
     ref_idx, ref_dk = ranking.hamming_topk_stable(q[:8], r, k)
     assert torch.equal(idx[:8].cpu().long(), ref_idx)
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine"])
+def test_float_knn_matches_reference_golden(gold, metric):
+    """get_knn float branches (get_knn.py:63-69) on the committed reference vectors.  Values: fp32
+    MFMA fmaf chain vs ATen's fp32 GEMM (cdist uses the |x|^2+|y|^2-2xy form above 25 rows):
+    atol 2e-5; indices equal wherever neighbouring values differ by more than that."""
+    q, r = torch.from_numpy(gold[f"float_{metric}/q"]), torch.from_numpy(gold[f"float_{metric}/r"])
+    idx, dist = get_knn(r, q, 20, False, with_faiss=False, distance_metric=metric)
+    ref_d, ref_i = gold[f"float_{metric}/dist"], gold[f"float_{metric}/idx"]
+    np.testing.assert_allclose(dist.cpu().numpy(), ref_d, atol=2e-5)
+    gaps = np.abs(np.diff(ref_d, axis=1)).min(axis=1) > 1e-4
+    assert gaps.sum() >= 5
+    np.testing.assert_array_equal(idx.cpu().numpy()[gaps], ref_i[gaps])
+
+
+@pytest.mark.parametrize("metric,Q,N,D,k", [("l2", 33, 3000, 128, 100), ("cosine", 17, 5000, 384, 5000),
+                                              ("hamming", 8, 777, 64, 50), ("l2", 5, 130, 12, 130)])
+def test_float_knn_seeded_against_oracle(metric, Q, N, D, k):
+    g = torch.Generator().manual_seed(Q * N)
+    q, r = torch.randn(Q, D, generator=g), torch.randn(N, D, generator=g)
+    if metric == "cosine":
+        q, r = torch.nn.functional.normalize(q), torch.nn.functional.normalize(r)
+    if metric == "hamming":                      # sign(0)-style codes: not +-1 -> float IP path
+        q, r = torch.sign(q), torch.sign(r)
+        r[0, 0] = 0.0
+    idx, dist = get_knn(r, q, k, False, distance_metric=metric)
+    sd, si = ranking.knn_stable(r, q, k, metric)
+    np.testing.assert_allclose(dist.cpu().numpy(), sd.numpy(), atol=3e-5 if metric != "hamming" else 0)
+    # every returned value is the true value of the returned index, and the list is sorted
+    full = (q @ r.t()) if metric != "l2" else torch.cdist(q, r)
+    np.testing.assert_allclose(torch.gather(full, 1, idx.cpu()).numpy(), dist.cpu().numpy(), atol=3e-5)
+    d = dist.cpu()
+    assert ((d[:, 1:] <= d[:, :-1] + 1e-6) if metric != "l2" else (d[:, 1:] >= d[:, :-1] - 1e-6)).all()
+    if metric == "hamming":                      # integer scores: exact, ties by ascending index
+        assert torch.equal(idx.cpu(), si)
+
+
+def test_get_accuracy_driver_metrics():
+    Q, N, nbits, k = 40, 3000, 64, 500
+    ql, rl = synth.multi_hot_labels(Q, 38, 0.10, 1), synth.multi_hot_labels(N, 38, 0.10, 2)
+    q, r = synth.structured_codes(ql, nbits, 3, 4), synth.structured_codes(rl, nbits, 3, 5)
+    from wvhash.engine import get_accuracy_calculator
+    calc = get_accuracy_calculator(k=k, distance_metric="hamming", with_faiss=False,
+                                   exclude=["mean_reciprocal_rank", "precision_at_1", "r_precision", "rpr"])
+    acc = calc.get_accuracy(q, ql, r, rl, False)
+    assert set(acc) == {"maphashing", "map", "bit_balance", "worst_bit_balance"}
+    m_st = ranking.calculate_maphashing(q, ql, r, rl, k, stable=True)
+    assert abs(acc["maphashing"] - m_st) < AP_TOL
+    # map_level0 = RetrievalMAP over the k-NN lists = same lists here -> same APs, mean over non-lone queries
+    sd, si = ranking.knn_stable(r, q, k, "hamming")
+    rel = torch.stack([ranking.label_comparison_fn(ql[i:i + 1], rl[si[i]])[0] for i in range(Q)])
+    assert abs(acc["map"] - ranking.retrieval_map(sd, rel)) < AP_TOL
+    assert abs(acc["bit_balance"] - ranking.calculate_bit_balance(r)) < 1e-6
+    idx, acc2 = calc.get_accuracy(q, ql, r, rl, False, return_indices=True)
+    assert torch.equal(idx.cpu(), si) and acc2 == acc
