@@ -1,0 +1,304 @@
+#!/usr/bin/env python3
+"""bench.py -- wavelet-hashing retrieval hot path on MI355X (contract: see the task brief).
+
+Workload (BASELINE.json configs[1], "c1"): MIRFLICKR-25k shape, 3-level db2 SWT, 64-bit hash,
+retrieval-only.  One STEP = one pass of the hot path over one batch of Q = 2048 synthetic query
+images per GPU, everything resident in HBM when the timed region starts:
+
+  images u8 [Q,224,224,3] --wv_swt2d_forward(db2, L3)--> sub-bands f32 [Q,3,4,224,224]
+  band CLS features f32 [4,Q,384] (synthetic: the DINOv2 backbone is outside the accelerated path,
+      SURVEY.md 8 a-13) --wv_band_attn_pool (Nq=4, fp32 MFMA)--> [Q,384]
+  --wv_hash_tail (hash_fc, BN, sign, pack)--> packed 64-bit query codes
+  --wv_hamming_topk vs 25,000 packed database codes, k=5000--> ranked lists
+  --wv_map_at_k--> AP per query -> mAP@5000
+
+N > 1 (one process per GPU, RCCL): weak scaling -- every rank embeds its own Q images, the database
+is row-sharded N ways; all_gather of the packed query codes, per-shard ranking of all N*Q queries,
+all_to_all of the per-shard lists, GPU merge (wvhash/parallel.py).  value = N*Q / step time.
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, live HIP-event timing),
+"kernels" (every stage), "cpu_baseline" (the oracle = CPU port of the reference's op sequence, timed
+on this host's cores on a bounded sample, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "image-retrieval-wavelet_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 measured copy)
+F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 (fp32 in/acc)
+
+Q_PER_GPU, N_DB, NBITS, TOPK, N_CLASSES = 2048, 25000, 64, 5000, 38
+H = W = 224
+WAVELET, LEVEL = "db2", 3
+EMBED, NQ, HEADS = 384, 4, 8
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--queries", type=int, default=Q_PER_GPU, help="query images per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-reps", type=int, default=10, help="launches per stage for the roofline timing")
+    return ap.parse_args()
+
+
+class Pipeline:
+    def __init__(self, Q, rank, world, device):
+        from wvhash import synth
+        from wvhash.engine import hamming as Hm
+        from wvhash.models import get_fusion_head
+        from wvhash.parallel import shard_bounds
+        self.Q, self.rank, self.world, self.dev = Q, rank, world, device
+        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        self.images = torch.randint(0, 256, (Q, H, W, 3), generator=g, dtype=torch.uint8).to(device)
+        self.feats = [f.to(device) for f in synth.band_features(Q, EMBED, seed=100 + rank)]
+        self.head = get_fusion_head({"type": "cross_attention_advanced", "output_dim": EMBED,
+                                     "num_heads": HEADS, "num_queries": NQ, "sub_band_dropout_p": 0,
+                                     "ortho_weight": 0.1}, [EMBED] * 4)
+        self.head.load_state_dict(synth.head_state(EMBED, NQ, "concat", seed=0))
+        self.head = self.head.to(device).eval()
+        tail = synth.hash_tail_state(EMBED, NBITS, seed=1)
+        self.hash_fc = torch.nn.Linear(EMBED, NBITS, bias=False)
+        self.bn = torch.nn.BatchNorm1d(NBITS)
+        self.hash_fc.load_state_dict({"weight": tail["hash_fc.weight"]})
+        self.bn.load_state_dict({k[3:]: v for k, v in tail.items() if k.startswith("bn.")})
+        self.hash_fc, self.bn = self.hash_fc.to(device).eval(), self.bn.to(device).eval()
+        # database: label-correlated codes (same on every rank), this rank keeps rows [lo, hi)
+        self.db_labels = synth.multi_hot_labels(N_DB, N_CLASSES, 0.10, seed=2)
+        db_codes = synth.structured_codes(self.db_labels, NBITS, 3, 5)
+        self.q_labels = synth.multi_hot_labels(Q, N_CLASSES, 0.10, seed=10 + rank)
+        self.lo, self.hi, _ = shard_bounds(N_DB, world, rank)
+        self.db_packed_full = Hm.pack_codes(db_codes.to(device))
+        self.db_shard = self.db_packed_full[self.lo:self.hi].contiguous()
+        self.dblab = Hm.pack_labels(self.db_labels.to(device))
+        self.qlab = Hm.pack_labels(self.q_labels.to(device))
+        self.ws = Hm.TopkWorkspace()
+        self.Hm = Hm
+        self.db_codes_cpu = db_codes
+
+    # -- the stages (each one C-ABI call) ---------------------------------------------------
+    def stage_swt(self):
+        from wvhash.transforms import swt2d
+        return swt2d(self.images, WAVELET, LEVEL, channels_last=True)
+
+    def stage_head(self):
+        return self.head(self.feats)
+
+    def stage_tail(self, fused):
+        from wvhash.models import hash_tail
+        return hash_tail(fused, self.hash_fc, self.bn, want=("packed",))["packed"]
+
+    def stage_rank(self, packed):
+        from wvhash.parallel import sharded_hamming_topk
+        return sharded_hamming_topk(packed, self.db_shard, NBITS, TOPK, N_DB, workspace=self.ws)
+
+    def stage_map(self, idx):
+        return self.Hm.map_at_k(idx, self.qlab, self.dblab)
+
+    @torch.no_grad()
+    def step(self):
+        bands = self.stage_swt()
+        fused = self.stage_head()
+        packed = self.stage_tail(fused)
+        idx, _ = self.stage_rank(packed)
+        ap, _ = self.stage_map(idx)
+        return bands, packed, idx, ap
+
+
+def time_stage(fn, reps):
+    """Average device time of one call (HIP events on the launch stream), ms."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def kernel_table(p, reps):
+    Q = p.Q
+    with torch.no_grad():
+        fused = p.stage_head()
+        packed = p.stage_tail(fused)
+        idx, _ = p.Hm.hamming_topk(packed, p.db_packed_full, NBITS, TOPK, workspace=p.ws)
+        rows = []
+        # algorithmic bytes / flops per launch (restated in DESIGN.md)
+        swt_bytes = Q * (3 * H * W * 1 + 3 * 4 * H * W * 4)
+        rows.append(("wv_swt2d_forward[k_swt_tiled db2 L3 u8->f32]", "hbm", swt_bytes,
+                     time_stage(p.stage_swt, reps)))
+        head_flops = Q * 14.2e6
+        rows.append(("wv_band_attn_pool[fp32 MFMA GEMMs + attn core + LN]", "mfma", head_flops,
+                     time_stage(p.stage_head, reps)))
+        tail_bytes = Q * (EMBED * 4 + 8) + NBITS * EMBED * 4
+        rows.append(("wv_hash_tail", "hbm", tail_bytes, time_stage(lambda: p.stage_tail(fused), reps)))
+        topk_bytes = (Q + N_DB) * NBITS // 8 + Q * TOPK * 5
+        rows.append(("wv_hamming_topk[k_hamming_topk 64b N=25000 k=5000]", "hbm", topk_bytes,
+                     time_stage(lambda: p.Hm.hamming_topk(packed, p.db_packed_full, NBITS, TOPK, workspace=p.ws), reps)))
+        dist_bytes = Q * N_DB + (Q + N_DB) * NBITS // 8
+        rows.append(("wv_hamming_dist[k_hamming_dist u8 matrix]", "hbm", dist_bytes,
+                     time_stage(lambda: p.Hm.hamming_dist(packed, p.db_packed_full), reps)))
+        map_bytes = Q * TOPK * 4 + (Q + N_DB) * 8 + Q * 8
+        rows.append(("wv_map_at_k", "hbm", map_bytes, time_stage(lambda: p.stage_map(idx), reps)))
+    out = []
+    for name, bound, work, ms in rows:
+        if bound == "hbm":
+            ach, peak, unit = work / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            ach, peak, unit = work / (ms * 1e-3) / 1e12, F32_MFMA_PEAK_TFLOPS, "TFLOP/s"
+        out.append({"kernel": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                    "frac": round(ach / peak, 4), "ms": round(ms, 4), "work_per_launch": work})
+    return out
+
+
+def load_traffic(kernel_name):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary (profiles/), if present."""
+    path = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        for key, val in t.items():
+            if key in kernel_name:
+                return val
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def cpu_baseline(p):
+    """The reference's op sequence on the host cores (oracle = CPU port), bounded sample."""
+    from oracle import head_torch, ranking, swt_np
+    from wvhash import synth
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    n_img, n_q = 24, 256
+    imgs = p.images[:n_img].cpu().numpy()
+    swt_np.c_transform_batch(imgs[:2], WAVELET, LEVEL)
+    t0 = time.perf_counter()
+    swt_np.c_transform_batch(imgs, WAVELET, LEVEL)       # per image, per channel, like the DataLoader worker
+    t_swt = (time.perf_counter() - t0) / n_img
+    sd = synth.head_state(EMBED, NQ, "concat", seed=0)
+    feats = [f[:n_q].cpu() for f in p.feats]
+    tail = synth.hash_tail_state(EMBED, NBITS, seed=1)
+    with torch.no_grad():
+        head_torch.band_attn_pool(feats, sd, HEADS)
+        t0 = time.perf_counter()
+        fused = head_torch.band_attn_pool(feats, sd, HEADS)
+        codes = head_torch.hash_tail(fused, tail["hash_fc.weight"], tail["bn.weight"], tail["bn.bias"],
+                                     tail["bn.running_mean"], tail["bn.running_var"])
+        t_head = (time.perf_counter() - t0) / n_q
+        codes[codes == 0] = 1.0
+        ql = p.q_labels[:n_q]
+        t0 = time.perf_counter()
+        m_ref, ap_ref = ranking.calculate_maphashing(codes, ql, p.db_codes_cpu, p.db_labels, TOPK,
+                                                     stable=True, return_per_query=True)
+        t_rank = (time.perf_counter() - t0) / n_q
+    # parity of the GPU path on the same sample (checker role of the oracle)
+    with torch.no_grad():
+        _, packed, idx, ap = p.step()
+    ap_gpu = ap[:n_q].cpu().numpy()
+    per_img = t_swt + t_head + t_rank
+    return {
+        "value": round(1.0 / per_img, 2), "unit": "query images/s", "cores": ncores, "kind": "port",
+        "sample": f"{n_img} images SWT (C oracle, 1 thread) + {n_q} queries head/hash + ranking loop "
+                  f"(torch CPU, {ncores} threads), N_db={N_DB}, k={TOPK}",
+        "ms_per_image": {"swt": round(t_swt * 1e3, 3), "head_hash": round(t_head * 1e3, 4),
+                         "rank_map": round(t_rank * 1e3, 3)},
+        "map_at_k_cpu_sample": round(m_ref, 6),
+        "max_abs_ap_diff_gpu_vs_cpu": float(np.abs(ap_gpu - np.asarray(ap_ref)).max()),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    p = Pipeline(args.queries, rank, world, device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = p.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = p.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ap = out[3]
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    ap_sum = ap.double().sum().reshape(1)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ap_sum)
+    elapsed = float(t.item())
+    total_q = args.queries * world
+    map_at_k = float(ap_sum.item()) / total_q
+
+    result = {
+        "metric": "query images/sec + mAP@5000, MIRFLICKR-25k 64-bit hash, 1/2/4/8 MI355X",
+        "value": round(total_q * args.steps / elapsed, 1),
+        "unit": "query images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (SWT, head) / u64 popcount (ranking)", "data": "synthetic",
+        "map_at_5000": round(map_at_k, 6),
+        "config": {
+            "workload": "c1: MIRFLICKR-25k shape, retrieval-only: per GPU per step 2048 query images "
+                        "224x224x3 u8 -> SWT db2 L3 -> band-attention head (Nq=4, E=384; DINOv2 backbone "
+                        "out of scope, CLS features synthetic) -> 64-bit hash -> Hamming top-5000 vs 25,000 "
+                        "codes -> mAP@5000",
+            "queries_per_gpu": args.queries, "db_codes": N_DB, "nbits": NBITS, "k": TOPK,
+            "wavelet": WAVELET, "level": LEVEL,
+            "parallelism": f"db row-sharded x{world}, all_gather(codes)+all_to_all(top-k lists)" if world > 1 else "single GPU",
+        },
+    }
+    if rank == 0 and world == 1:
+        kt = kernel_table(p, args.kernel_reps)
+        dom = max((k for k in kt if not k["kernel"].startswith("wv_hamming_dist")), key=lambda k: k["ms"])
+        result["roofline"] = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"],
+                              "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
+                              "traffic": load_traffic(dom["kernel"])}
+        result["kernels"] = kt
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(p)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -19,7 +19,7 @@
 namespace wv {
 
 constexpr int kTopkThreads = 256;
-constexpr int kMaxBins = 129;  // nbits <= 128
+constexpr int kMaxBins = 130;  // nbits <= 128 (+1 bin for the padding value of ragged shard lists)
 
 // ------------------------------------------------------------------------ item sources
 // CodeSource: items are database codes, distance = popcount(q ^ code), id = row + offset
@@ -373,7 +373,7 @@ extern "C" int wv_topk_merge(const int32_t *idx_in, const uint8_t *dist_in, int 
     if (Q == 0) return WV_OK;
     const int64_t items = (int64_t)G * kin;
     const int C = (int)ceil_div(items, kTopkThreads);
-    const int nbins = nbits + 1;
+    const int nbins = nbits + 2;  // dist = nbits + 1 marks padding entries: they rank after every real one
     const size_t lds = rank_lds_bytes(nbins);
     int rc = set_lds_attr(reinterpret_cast<const void *>(k_topk_merge), lds, "topk_merge");
     if (rc) return rc;

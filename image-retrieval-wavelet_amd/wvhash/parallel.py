@@ -1,0 +1,64 @@
+"""Database-sharded Hamming retrieval across the GPUs of one node (one process per GPU, RCCL).
+
+Reference analogue: faiss.index_cpu_to_all_gpus(index, co) with co.shards = True
+(/root/reference/main/engine/get_knn.py:41-44): database rows split across GPUs, brute-force search
+per shard, per-shard top-k merged on the HOST.  Here the shards stay resident in HBM as packed codes,
+and the only exchange steps are
+  1. all_gather of the packed query codes (Q * nbits/8 bytes per rank -- tiny), so every rank can rank
+     every query against its shard;
+  2. all_to_all of the per-shard top-k lists (int32 index + uint8 distance): rank r receives, from
+     every shard, the lists of ITS queries only (an all_gather would move world_size times more);
+  3. a local G-way merge on the GPU (wv_topk_merge), exact and identical for every world size because
+     lists are ordered by (distance, global index) and shards are contiguous row ranges in rank order.
+xGMI is point-to-point: with 8 GPUs fully connected both collectives are one direct exchange per peer.
+"""
+import torch
+import torch.distributed as dist
+
+from .engine import hamming as H
+
+
+def shard_bounds(n_rows, world_size, rank):
+    per = (n_rows + world_size - 1) // world_size
+    lo = min(n_rows, rank * per)
+    hi = min(n_rows, lo + per)
+    return lo, hi, per
+
+
+def pad_value(nbits):
+    """Distance assigned to padding entries of ragged shard lists: sorts after every real entry."""
+    return nbits + 1
+
+
+def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, workspace=None):
+    """q_local: packed codes of THIS rank's queries [Ql, words]; db_shard: this rank's rows
+    [lo:hi] of the packed database.  Returns the global (idx int32 [Ql,k], dist uint8 [Ql,k]) of the
+    local queries.  Every rank must call with the same Ql."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return H.hamming_topk(q_local, db_shard, nbits, k, workspace=workspace)
+    rank = dist.get_rank(group)
+    Ql, words = q_local.shape
+    lo, hi, per = shard_bounds(n_total, world, rank)
+    kin = min(k, per)                                   # list length every shard sends (padded)
+    # 1. every rank needs every query
+    q_all = torch.empty((world * Ql, words), dtype=q_local.dtype, device=q_local.device)
+    dist.all_gather_into_tensor(q_all, q_local.contiguous(), group=group)
+    # 2. rank all queries against the local shard
+    n_local = hi - lo
+    k_local = min(kin, n_local)
+    idx_s = torch.full((world * Ql, kin), -1, dtype=torch.int32, device=q_local.device)
+    dist_s = torch.full((world * Ql, kin), pad_value(nbits), dtype=torch.uint8, device=q_local.device)
+    if k_local > 0:
+        i, d = H.hamming_topk(q_all, db_shard, nbits, k_local, idx_offset=lo, workspace=workspace)
+        if k_local == kin:
+            idx_s, dist_s = i, d
+        else:
+            idx_s[:, :k_local], dist_s[:, :k_local] = i, d
+    # 3. exchange: block j of my lists (queries of rank j) goes to rank j
+    idx_r = torch.empty_like(idx_s)
+    dist_r = torch.empty_like(dist_s)
+    dist.all_to_all_single(idx_r, idx_s.contiguous(), group=group)
+    dist.all_to_all_single(dist_r, dist_s.contiguous(), group=group)
+    # received layout: [shard g][my Ql queries][kin]  ->  merge
+    return H.topk_merge(idx_r.view(world, Ql, kin), dist_r.view(world, Ql, kin), k, nbits)

@@ -111,7 +111,8 @@ int wv_hamming_topk(const uint64_t *q, const uint64_t *db, int32_t *idx, uint8_t
  * Replaces the host-side shard merge inside faiss.index_cpu_to_all_gpus(shards=True)
  *   (get_knn.py:41-44).  Lists must come from contiguous row shards in rank order, so that
  * ascending global index inside a distance bucket = (shard, position) order.
- * idx_in/dist_in: [G][Q][kin];  idx_out/dist_out: [Q][k], k <= G*kin. nbits <= 128. */
+ * idx_in/dist_in: [G][Q][kin];  idx_out/dist_out: [Q][k], k <= G*kin. nbits <= 128.
+ * Shorter lists are padded with dist = nbits + 1 (idx = -1): such entries rank after every real one. */
 int wv_topk_merge(const int32_t *idx_in, const uint8_t *dist_in, int G, int Q, int kin,
                   int32_t *idx_out, uint8_t *dist_out, int k, int nbits, void *stream);
 
