@@ -184,7 +184,8 @@ def cpu_baseline(p):
     """The reference's op sequence on the host cores (oracle = CPU port), bounded sample."""
     from oracle import head_torch, ranking, swt_np
     from wvhash import synth
-    ncores = os.cpu_count() or 1
+    # threads actually usable: the affinity mask, capped at the GPU box's 16-core share per GPU
+    ncores = min(len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(ncores)
     n_img, n_q = 24, 256
     imgs = p.images[:n_img].cpu().numpy()
