@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstdio>
+#include <cstring>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>

@@ -21,6 +21,7 @@
 // Generic kernels (k_axis_generic): any tap count / any size, one level per launch through a
 // caller workspace; used only when the tiled kernel's constraints do not hold.
 #include "common.hpp"
+#include "swt_fused.hpp"
 
 namespace wv {
 
@@ -533,9 +534,17 @@ template <typename InT, typename OutT>
 static int swt_typed(const void *in, void *out, int B, int C, int H, int W, int n, const float *lo,
                      const float *hi, int L, int in_layout, void *ws, size_t ws_bytes, hipStream_t st)
 {
-    const char *force = getenv("WV_SWT_FORCE_GENERIC");
+    // WV_SWT_PATH = fused | tiled | generic pins one implementation (tests / tuning); default: best available
+    const char *path = getenv("WV_SWT_PATH");
+    const bool want_fused = !path || !strcmp(path, "fused");
+    const bool want_tiled = !path || !strcmp(path, "tiled");
+    if (want_fused && swt_fused_covers(L, n, W)) {
+        const int rc = swt_fused_launch(in, sizeof(InT) == 1 ? WV_DT_U8 : WV_DT_F32, in_layout, out,
+                                        sizeof(OutT) == 2 ? WV_DT_BF16 : WV_DT_F32, B, C, H, W, n, lo, hi, L, st);
+        if (rc <= 0) return rc;
+    }
     TilePlan p = plan_tiles(B, C, H, W, L, n, in_layout);
-    if (p.ok && !(force && force[0] == '1')) return dispatch_taps<InT, OutT>(L, n, in, out, p, lo, hi, st);
+    if (want_tiled && p.ok) return dispatch_taps<InT, OutT>(L, n, in, out, p, lo, hi, st);
     return run_generic<InT, OutT>(in, out, B, C, H, W, n, lo, hi, L, in_layout, ws, ws_bytes, st);
 }
 
@@ -546,9 +555,12 @@ using namespace wv;
 extern "C" size_t wv_swt2d_workspace_bytes(int B, int C, int H, int W, int level, int flen)
 {
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
-    const char *force = getenv("WV_SWT_FORCE_GENERIC");
-    TilePlan p = plan_tiles(B, C, H, W, flen, level, WV_LAYOUT_NCHW);
-    if (p.ok && !(force && force[0] == '1')) return 0;
+    const char *path = getenv("WV_SWT_PATH");
+    if (!path || strcmp(path, "generic")) {
+        if (swt_fused_covers(flen, level, W) && (!path || !strcmp(path, "fused"))) return 0;
+        TilePlan p = plan_tiles(B, C, H, W, flen, level, WV_LAYOUT_NCHW);
+        if (p.ok && (!path || !strcmp(path, "tiled"))) return 0;
+    }
     return (size_t)3 * B * C * H * W * sizeof(float);
 }
 

@@ -1,0 +1,11 @@
+// Entry points of the register-fused two-pass SWT kernel (swt_fused.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace wv {
+// true when the (taps, levels, width) combination has a fused instantiation
+bool swt_fused_covers(int L, int n, int W);
+// returns WV_OK / negative error, or 1 when the shape is not covered
+int swt_fused_launch(const void *in, int in_dtype, int in_layout, void *out, int out_dtype, int B, int C, int H,
+                     int W, int n, const float *lo, const float *hi, int L, hipStream_t st);
+}  // namespace wv
