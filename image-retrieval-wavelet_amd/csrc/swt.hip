@@ -536,8 +536,14 @@ static int swt_typed(const void *in, void *out, int B, int C, int H, int W, int 
 {
     // WV_SWT_PATH = fused | tiled | generic pins one implementation (tests / tuning); default: best available
     const char *path = getenv("WV_SWT_PATH");
+    const bool want_slide = !path || !strcmp(path, "slide");
     const bool want_fused = !path || !strcmp(path, "fused");
     const bool want_tiled = !path || !strcmp(path, "tiled");
+    if (want_slide && swt_slide_covers(L, n, W, H)) {
+        const int rc = swt_slide_launch(in, sizeof(InT) == 1 ? WV_DT_U8 : WV_DT_F32, in_layout, out,
+                                        sizeof(OutT) == 2 ? WV_DT_BF16 : WV_DT_F32, B, C, H, W, n, lo, hi, L, st);
+        if (rc <= 0) return rc;
+    }
     if (want_fused && swt_fused_covers(L, n, W)) {
         const int rc = swt_fused_launch(in, sizeof(InT) == 1 ? WV_DT_U8 : WV_DT_F32, in_layout, out,
                                         sizeof(OutT) == 2 ? WV_DT_BF16 : WV_DT_F32, B, C, H, W, n, lo, hi, L, st);
@@ -557,6 +563,7 @@ extern "C" size_t wv_swt2d_workspace_bytes(int B, int C, int H, int W, int level
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
     const char *path = getenv("WV_SWT_PATH");
     if (!path || strcmp(path, "generic")) {
+        if (swt_slide_covers(flen, level, W, H) && (!path || !strcmp(path, "slide"))) return 0;
         if (swt_fused_covers(flen, level, W) && (!path || !strcmp(path, "fused"))) return 0;
         TilePlan p = plan_tiles(B, C, H, W, flen, level, WV_LAYOUT_NCHW);
         if (p.ok && (!path || !strcmp(path, "tiled"))) return 0;

@@ -1,0 +1,95 @@
+// Micro-test: how fast can the SWT output pattern be written?  (build: hipcc --offload-arch=gfx950)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+constexpr int H = 224, W = 224, TH = 32, TW = 112;
+
+// A: thread = (plane, column): 32 rows x 2 bands of dword stores (the fused kernel's V pass)
+__global__ __launch_bounds__(256) void kA(float *out, float v)
+{
+    const int tile = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+    const int ty = tile / 2, tx = tile % 2, x0 = tx * TW, y0 = ty * TH;
+    const size_t band = (size_t)H * W;
+    for (int u = threadIdx.x; u < 2 * TW; u += 256) {
+        const int pl = u / TW, x = u - pl * TW;
+        const size_t base = (((size_t)b * 3 + c) * 4 + 2 * pl) * band + (size_t)y0 * W + x0 + x;
+#pragma unroll
+        for (int i = 0; i < TH; ++i) {
+            out[base + (size_t)i * W] = v + i;
+            out[base + band + (size_t)i * W] = v - i;
+        }
+    }
+}
+// B: thread = (band, row, 4 columns): float4 stores, lanes along x
+__global__ __launch_bounds__(256) void kB(float *out, float v)
+{
+    const int tile = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+    const int ty = tile / 2, tx = tile % 2, x0 = tx * TW, y0 = ty * TH;
+    const size_t band = (size_t)H * W;
+    for (int u = threadIdx.x; u < 4 * TH * (TW / 4); u += 256) {
+        const int xq = u % (TW / 4), r = (u / (TW / 4)) % TH, bd = u / ((TW / 4) * TH);
+        float4 val = make_float4(v, v + 1, v + 2, v + r);
+        *reinterpret_cast<float4 *>(out + (((size_t)b * 3 + c) * 4 + bd) * band + (size_t)(y0 + r) * W + x0 + 4 * xq) = val;
+    }
+}
+// C: flat streaming float4 fill
+__global__ __launch_bounds__(256) void kC(float4 *out, size_t n4, float v)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+        out[i] = make_float4(v, v, v, v);
+}
+// D: full-width tiles (TH rows x 224): per band one contiguous TH*896 B block; thread = (plane, column), 512 threads
+template <int THD, int NT>
+__global__ __launch_bounds__(NT) void kD(float *out, float v)
+{
+    const int ty = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+    const int y0 = ty * THD;
+    const size_t band = (size_t)H * W;
+    for (int u = threadIdx.x; u < 2 * W; u += NT) {
+        const int pl = u / W, x = u - pl * W;
+        const size_t base = (((size_t)b * 3 + c) * 4 + 2 * pl) * band + (size_t)y0 * W + x;
+#pragma unroll
+        for (int i = 0; i < THD; ++i) {
+            out[base + (size_t)i * W] = v + i;
+            out[base + band + (size_t)i * W] = v - i;
+        }
+    }
+}
+// E: whole (image, channel) plane per workgroup, persistent over planes: 4 bands x 200 KB contiguous each
+__global__ __launch_bounds__(256) void kE(float *out, float v, int planes)
+{
+    const size_t band = (size_t)H * W;
+    for (int p = blockIdx.x; p < planes; p += gridDim.x) {
+        float4 *o = reinterpret_cast<float4 *>(out + (size_t)p * 4 * band);
+        for (int i = threadIdx.x; i < 4 * H * W / 4; i += 256) o[i] = make_float4(v, v, v, v + i);
+    }
+}
+int main()
+{
+    const int B = 2048;
+    const size_t n = (size_t)B * 3 * 4 * H * W;
+    float *out;
+    CK(hipMalloc(&out, n * 4));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int which = 0; which < 7; ++which) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 5; ++rep) {
+            CK(hipEventRecord(e0));
+            if (which == 0) hipLaunchKernelGGL(kA, dim3(14, 3, B), dim3(256), 0, 0, out, 1.0f);
+            if (which == 1) hipLaunchKernelGGL(kB, dim3(14, 3, B), dim3(256), 0, 0, out, 1.0f);
+            if (which == 2) hipLaunchKernelGGL(kC, dim3(256 * 8), dim3(256), 0, 0, (float4 *)out, n / 4, 1.0f);
+            if (which == 3) hipLaunchKernelGGL((kD<32, 512>), dim3(7, 3, B), dim3(512), 0, 0, out, 1.0f);
+            if (which == 4) hipLaunchKernelGGL((kD<16, 512>), dim3(14, 3, B), dim3(512), 0, 0, out, 1.0f);
+            if (which == 5) hipLaunchKernelGGL((kD<56, 512>), dim3(4, 3, B), dim3(512), 0, 0, out, 1.0f);
+            if (which == 6) hipLaunchKernelGGL(kE, dim3(256 * 4), dim3(256), 0, 0, out, 1.0f, 3 * B);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) best = ms;
+        }
+        printf("pattern %c: %.3f ms  %.0f GB/s\n", 'A' + which, best, n * 4 / best / 1e6);
+    }
+    return 0;
+}
