@@ -63,6 +63,74 @@ struct SChain {
     }
 };
 
+// Streaming form of the same cascade for pass V: a thread keeps, per column, the last (L-1)*2^(l-1)
+// inputs of every level l in registers ("tails", HALO values in all), so each step costs exactly
+// L MACs per level per new row -- no halo recompute -- and emits outputs delayed by HALO rows.
+// The arithmetic per output is identical to SChain (same taps, same order).
+template <int L, int NLEV, int N>
+struct VStep {
+    static constexpr int HALO = (L - 1) * ((1 << NLEV) - 1);
+    // levels LEV .. NLEV-1: cur[] holds N new level-LEV inputs on entry, N new level-NLEV inputs on exit
+    template <int LEV>
+    static __device__ __forceinline__ void lower(float (&cur)[N], float (&tail)[HALO], const float (&lo)[L])
+    {
+        if constexpr (LEV < NLEV) {
+            constexpr int S = 1 << (LEV - 1), T = (L - 1) * S, OFF = (L - 1) * (S - 1);
+            float seq[T + N];
+#pragma unroll
+            for (int i = 0; i < T; ++i) seq[i] = tail[OFF + i];
+#pragma unroll
+            for (int i = 0; i < N; ++i) seq[T + i] = cur[i];
+#pragma unroll
+            for (int t = 0; t < N; ++t) {
+                float a = lo[0] * seq[t + S * (L - 1)];
+#pragma unroll
+                for (int m = 1; m < L; ++m) a = fmaf(lo[m], seq[t + S * (L - 1 - m)], a);
+                cur[t] = a;
+            }
+#pragma unroll
+            for (int i = 0; i < T; ++i) tail[OFF + i] = seq[N + i];
+            lower<LEV + 1>(cur, tail, lo);
+        }
+    }
+    // last level: seq = tail ++ cur; out(t) for t < N; tail updated
+    template <typename Emit>
+    static __device__ __forceinline__ void last(const float (&cur)[N], float (&tail)[HALO], const float (&lo)[L],
+                                                const float (&hi)[L], Emit emit)
+    {
+        constexpr int S = 1 << (NLEV - 1), T = (L - 1) * S, OFF = (L - 1) * (S - 1);
+        float seq[T + N];
+#pragma unroll
+        for (int i = 0; i < T; ++i) seq[i] = tail[OFF + i];
+#pragma unroll
+        for (int i = 0; i < N; ++i) seq[T + i] = cur[i];
+#pragma unroll
+        for (int t = 0; t < N; ++t) {
+            float a = lo[0] * seq[t + S * (L - 1)], d = hi[0] * seq[t + S * (L - 1)];
+#pragma unroll
+            for (int m = 1; m < L; ++m) {
+                a = fmaf(lo[m], seq[t + S * (L - 1 - m)], a);
+                d = fmaf(hi[m], seq[t + S * (L - 1 - m)], d);
+            }
+            emit(t, a, d);
+        }
+#pragma unroll
+        for (int i = 0; i < T; ++i) tail[OFF + i] = seq[N + i];
+    }
+    // warm-up: only refresh the last level's tail
+    static __device__ __forceinline__ void prime_last(const float (&cur)[N], float (&tail)[HALO])
+    {
+        constexpr int S = 1 << (NLEV - 1), T = (L - 1) * S, OFF = (L - 1) * (S - 1);
+        float seq[T + N];
+#pragma unroll
+        for (int i = 0; i < T; ++i) seq[i] = tail[OFF + i];
+#pragma unroll
+        for (int i = 0; i < N; ++i) seq[T + i] = cur[i];
+#pragma unroll
+        for (int i = 0; i < T; ++i) tail[OFF + i] = seq[N + i];
+    }
+};
+
 // branch-free wrap, valid for -n <= v < 2n (guaranteed by swt_slide_covers)
 __device__ __forceinline__ int swrap1(int v, int n)
 {
@@ -137,135 +205,142 @@ __device__ __forceinline__ float4 s_convert4(const SRaw<InT, LAYOUT> &r, int c)
     }
 }
 
-template <int L, int NLEV, int R, int TH, int NT, typename InT, int LAYOUT, bool BF16>
-__global__ __launch_bounds__(NT) void k_swt_slide(const InT *__restrict__ in, void *__restrict__ out,
-                                                  SlideGeom g, STaps<L> taps)
+// Producer / consumer split inside one workgroup of 2 * NH threads:
+//   waves [NH/64, 2*NH/64)  "H waves": fetch the TH input rows of chunk k+1, filter them along x in
+//                           registers (all levels) and write lo / hi into LDS buffer (k+1) & 1
+//   waves [0, NH/64)        "V waves": thread = column; stream chunk k of both planes from LDS buffer
+//                           k & 1 through the per-column cascade (tails in registers) and store the TH
+//                           output rows the cascade emits (it lags the input by HALO rows)
+// One barrier per chunk hands the buffers over.  Each role needs well under 128 VGPRs, so two
+// workgroups (16 waves) fit a CU and the two halves of every SIMD pair overlap load latency,
+// row arithmetic, column arithmetic and the output stream.
+template <int L, int NLEV, int R, int TH, int NH, int MINW, typename InT, int LAYOUT, bool BF16>
+__global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restrict__ in, void *__restrict__ out,
+                                                            SlideGeom g, STaps<L> taps)
 {
     using CH = SChain<L, NLEV, R>;
-    using CV = SChain<L, NLEV, TH>;
     using Raw = SRaw<InT, LAYOUT>;
     using OutT = typename std::conditional<BF16, __hip_bfloat16, float>::type;
     constexpr int HALO = CH::HALO;
     constexpr int HB = (L / 2 - 1) * ((1 << NLEV) - 1);
-    constexpr int HA = HALO - HB;
     constexpr int HBa = (HB + 3) / 4 * 4;
-    constexpr int RH = TH + HALO;
     constexpr int NG = (HBa - HB + CH::NIN + 3) / 4;      // 4-pixel groups one run loads
     static_assert(R % 4 == 0, "run length must be a multiple of 4");
     extern __shared__ float4 ring4[];
-    float *ring = reinterpret_cast<float *>(ring4);       // [2][RH][P]
+    float *ring = reinterpret_cast<float *>(ring4);       // [2 buffers][2 planes][TH][P]
     const int P = g.P, W = g.W, H = g.H;
-    const int plane_sz = RH * P;
-    const int nsteps = (H + TH - 1) / TH;
+    const int plane_sz = TH * P, buf_sz = 2 * plane_sz;
+    const int nchunks = (H + HALO + TH - 1) / TH;         // the cascade consumes H + HALO rows per plane
     const uint32_t band = (uint32_t)H * W;
     const int nplanes = g.B * g.C;
-    const int units = TH * g.nrun;                        // <= NT (checked on the host)
-    // this thread's (row-in-step, run) for pass H
-    const int h_rr = threadIdx.x / g.nrun, h_j = threadIdx.x - h_rr * g.nrun;
-    const bool h_active = (int)threadIdx.x < units;
+    const bool is_h = threadIdx.x >= NH;                  // wave-uniform role
+    const int t = is_h ? threadIdx.x - NH : threadIdx.x;
 
-    auto fetch_unit = [&](Raw (&raw)[NG], const InT *img, int c, int y, int j) {
-        const uint32_t row = (uint32_t)swrap1(y, H) * (uint32_t)W;
-        const int gx0 = j * R - HBa;
-#pragma unroll
-        for (int k = 0; k < NG; ++k) raw[k] = s_fetch4<InT, LAYOUT>(img, row + (uint32_t)swrap1(gx0 + 4 * k, W), c);
-    };
-    auto hpass_unit = [&](const Raw (&raw)[NG], int c, int slot, int j) {
-        float px[NG * 4];
-#pragma unroll
-        for (int k = 0; k < NG; ++k) {
-            const float4 p4 = s_convert4<InT, LAYOUT>(raw[k], c);
-            px[4 * k + 0] = p4.x; px[4 * k + 1] = p4.y; px[4 * k + 2] = p4.z; px[4 * k + 3] = p4.w;
-        }
-        float v[CH::NIN];
-#pragma unroll
-        for (int i = 0; i < CH::NIN; ++i) v[i] = px[i + (HBa - HB)];
-        CH::template lower<1>(v, taps.lo);
-        float *plo = ring + slot * P + j * R;
-        float *phi = plo + plane_sz;
-#pragma unroll
-        for (int q4 = 0; q4 < R / 4; ++q4) {
-            float4 lo4, hi4;
-            lo4.x = CH::last(v, taps.lo, 4 * q4 + 0); hi4.x = CH::last(v, taps.hi, 4 * q4 + 0);
-            lo4.y = CH::last(v, taps.lo, 4 * q4 + 1); hi4.y = CH::last(v, taps.hi, 4 * q4 + 1);
-            lo4.z = CH::last(v, taps.lo, 4 * q4 + 2); hi4.z = CH::last(v, taps.hi, 4 * q4 + 2);
-            lo4.w = CH::last(v, taps.lo, 4 * q4 + 3); hi4.w = CH::last(v, taps.hi, 4 * q4 + 3);
-            *reinterpret_cast<float4 *>(plo + 4 * q4) = lo4;
-            *reinterpret_cast<float4 *>(phi + 4 * q4) = hi4;
-        }
-    };
-
-    for (int pc = blockIdx.x; pc < nplanes; pc += gridDim.x) {
-        const int b = pc / g.C, c = pc - b * g.C;
-        // uniform base of the pixels this plane reads
-        const InT *img = LAYOUT == 0 ? in + (size_t)pc * band : in + (size_t)b * band * 3;
-        OutT *oplane = reinterpret_cast<OutT *>(out) + (size_t)pc * 4 * band;
-        // ---- prologue: the HALO rows around the first block (y in [-HB, HA)) -> slots 0 .. HALO-1
-        for (int u = threadIdx.x; u < HALO * g.nrun; u += NT) {
-            const int rr = u / g.nrun, j = u - rr * g.nrun;
+    if (is_h) {
+        // ------------------------------------------------------------------ producer: pass H
+        const int rr = t / g.nrun, j = t - rr * g.nrun;
+        const bool active = t < TH * g.nrun;
+        for (int pc = blockIdx.x; pc < nplanes; pc += gridDim.x) {
+            const int b = pc / g.C, c = pc - b * g.C;
+            const InT *img = LAYOUT == 0 ? in + (size_t)pc * band : in + (size_t)b * band * 3;
             Raw raw[NG];
-            fetch_unit(raw, img, c, rr - HB, j);
-            hpass_unit(raw, c, rr, j);
-        }
-        Raw pre[NG];
-        if (h_active) fetch_unit(pre, img, c, HA + h_rr, h_j);
-        int slot_new = HALO;     // ring slot of the first new row of the step ((y0 + HALO) % RH)
-        int s0 = 0;              // ring slot of virtual row y0 (= y0 % RH)
-        for (int s = 0; s < nsteps; ++s) {
-            const int y0 = s * TH;
-            // ---- pass H on the TH new rows y0 + HA .. y0 + HA + TH - 1 (prefetched)
-            if (h_active) {
-                int slot = slot_new + h_rr;
-                slot = slot >= RH ? slot - RH : slot;
-                hpass_unit(pre, c, slot, h_j);
-            }
-            __syncthreads();
-            // ---- prefetch the raw pixels of the next step (hidden behind pass V)
-            if (h_active && s + 1 < nsteps) fetch_unit(pre, img, c, y0 + TH + HA + h_rr, h_j);
-            // ---- pass V: ring rows s0 .. s0 + RH - 1 (mod RH) -> output rows y0 .. y0 + TH - 1
-            OutT *orow0 = oplane + (size_t)y0 * W;   // uniform
-            for (int u = threadIdx.x; u < 2 * W; u += NT) {
-                const int pl = u >= W ? 1 : 0, x = u - pl * W;
-                const float *col = ring + pl * plane_sz + x;
-                float v[CV::NIN];
+            auto fetch = [&](int chunk) {
+                // input row of virtual row v = chunk*TH + rr is y = v - HB (wrapped; rows past H + HA wrap too)
+                int y = chunk * TH + rr - HB;
+                y = y >= H ? y - H : y;
+                const uint32_t row = (uint32_t)swrap1(y, H) * (uint32_t)W;
+                const int gx0 = j * R - HBa;
 #pragma unroll
-                for (int i = 0; i < CV::NIN; ++i) {
-                    int slot = s0 + i;
-                    slot = slot >= RH ? slot - RH : slot;
-                    v[i] = col[slot * P];
-                }
-                CV::template lower<1>(v, taps.lo);
-                const uint32_t lane_off = (uint32_t)(2 * pl) * band + (uint32_t)x;   // < 2^32 (host check)
+                for (int k = 0; k < NG; ++k)
+                    raw[k] = s_fetch4<InT, LAYOUT>(img, row + (uint32_t)swrap1(gx0 + 4 * k, W), c);
+            };
+            if (active) fetch(0);
+            for (int k = 0; k < nchunks; ++k) {
+                if (active) {
+                    float v[NG * 4];
 #pragma unroll
-                for (int i = 0; i < TH; ++i) {
-                    if (y0 + i < H) {
-                        OutT *orow = orow0 + (size_t)i * W;   // uniform
-                        orow[lane_off] = (OutT)CV::last(v, taps.lo, i);
-                        orow[lane_off + band] = (OutT)CV::last(v, taps.hi, i);
+                    for (int q = 0; q < NG; ++q) {
+                        const float4 p4 = s_convert4<InT, LAYOUT>(raw[q], c);
+                        v[4 * q + 0] = p4.x; v[4 * q + 1] = p4.y; v[4 * q + 2] = p4.z; v[4 * q + 3] = p4.w;
+                    }
+                    if (k + 1 < nchunks) fetch(k + 1);     // next chunk's pixels fly during the arithmetic
+                    // in-place cascade on v[off ..): element i of the run lives at v[i + off]
+                    constexpr int off = HBa - HB;
+                    float w[CH::NIN];
+#pragma unroll
+                    for (int i = 0; i < CH::NIN; ++i) w[i] = v[i + off];
+                    CH::template lower<1>(w, taps.lo);
+                    float *plo = ring + (k & 1) * buf_sz + rr * P + j * R;
+                    float *phi = plo + plane_sz;
+#pragma unroll
+                    for (int q4 = 0; q4 < R / 4; ++q4) {
+                        float4 lo4, hi4;
+                        lo4.x = CH::last(w, taps.lo, 4 * q4 + 0); hi4.x = CH::last(w, taps.hi, 4 * q4 + 0);
+                        lo4.y = CH::last(w, taps.lo, 4 * q4 + 1); hi4.y = CH::last(w, taps.hi, 4 * q4 + 1);
+                        lo4.z = CH::last(w, taps.lo, 4 * q4 + 2); hi4.z = CH::last(w, taps.hi, 4 * q4 + 2);
+                        lo4.w = CH::last(w, taps.lo, 4 * q4 + 3); hi4.w = CH::last(w, taps.hi, 4 * q4 + 3);
+                        *reinterpret_cast<float4 *>(plo + 4 * q4) = lo4;
+                        *reinterpret_cast<float4 *>(phi + 4 * q4) = hi4;
                     }
                 }
+                __syncthreads();   // buffer k & 1 is full; buffer (k+1) & 1 was drained before this barrier
             }
-            __syncthreads();
-            slot_new += TH; slot_new = slot_new >= RH ? slot_new - RH : slot_new;
-            s0 += TH; s0 = s0 >= RH ? s0 - RH : s0;
+            __syncthreads();       // pairs with the consumer's last barrier of the plane
+        }
+    } else {
+        // ------------------------------------------------------------------ consumer: pass V
+        const bool active = t < W;
+        for (int pc = blockIdx.x; pc < nplanes; pc += gridDim.x) {
+            OutT *oplane = reinterpret_cast<OutT *>(out) + (size_t)pc * 4 * band;
+            float tail[2][HALO];
+#pragma unroll
+            for (int i = 0; i < HALO; ++i) tail[0][i] = tail[1][i] = 0.f;
+            __syncthreads();       // chunk 0 produced
+            for (int k = 0; k < nchunks; ++k) {
+                const int y0 = k * TH - HALO;              // first output row this chunk emits (uniform)
+                if (active) {
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        const float *col = ring + (k & 1) * buf_sz + pl * plane_sz + t;
+                        float cur[TH];
+#pragma unroll
+                        for (int i = 0; i < TH; ++i) cur[i] = col[i * P];
+                        VStep<L, NLEV, TH>::template lower<1>(cur, tail[pl], taps.lo);
+                        if (y0 + TH <= 0) {               // nothing to emit yet: only advance the state
+                            VStep<L, NLEV, TH>::prime_last(cur, tail[pl]);
+                        } else {
+                            const uint32_t lane_off = (uint32_t)(2 * pl) * band + (uint32_t)t;
+                            VStep<L, NLEV, TH>::last(cur, tail[pl], taps.lo, taps.hi, [&](int i, float a, float d) {
+                                const int y = y0 + i;
+                                if (y >= 0 && y < H) {
+                                    OutT *orow = oplane + (size_t)y * W;   // uniform
+                                    orow[lane_off] = (OutT)a;
+                                    orow[lane_off + band] = (OutT)d;
+                                }
+                            });
+                        }
+                    }
+                }
+                __syncthreads();   // buffer k & 1 drained, buffer (k+1) & 1 full
+            }
         }
     }
 }
 
-template <int L, int NLEV, int R, int TH, int NT, typename InT, int LAYOUT, bool BF16>
+template <int L, int NLEV, int R, int TH, int NT, int MINW, typename InT, int LAYOUT, bool BF16>
 static int launch_slide(const void *in, void *out, SlideGeom g, const float *lo, const float *hi, hipStream_t st)
 {
     constexpr int HALO = (L - 1) * ((1 << NLEV) - 1);
-    constexpr int RH = TH + HALO;
     STaps<L> taps;
     for (int i = 0; i < L; ++i) { taps.lo[i] = lo[i]; taps.hi[i] = hi[i]; }
     g.nrun = (int)ceil_div(g.W, R);
     g.P = g.nrun * R + 4;                         // multiple of 4; rows hold whole runs
-    const size_t lds = (size_t)2 * RH * g.P * sizeof(float);
+    const size_t lds = (size_t)2 * 2 * TH * g.P * sizeof(float);  // 2 buffers x 2 planes
     // shapes this kernel does not take: the caller falls back to the tiled kernels
-    if (lds > (size_t)kMaxLdsBytes - 2048 || TH * g.nrun > NT) return 1;
-    if (g.W < R + HALO || g.H < TH + HALO || (uint64_t)g.H * g.W * 4 >= (1ull << 30)) return 1;
-    auto kern = k_swt_slide<L, NLEV, R, TH, NT, InT, LAYOUT, BF16>;
+    if (lds > (size_t)kMaxLdsBytes - 2048 || TH * g.nrun > NT || g.W > NT) return 1;
+    (void)HALO;
+    if (g.W < R + HALO || g.H < TH + 2 * HALO || (uint64_t)g.H * g.W * 4 >= (1ull << 30)) return 1;
+    auto kern = k_swt_slide<L, NLEV, R, TH, NT, MINW, InT, LAYOUT, BF16>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -281,21 +356,21 @@ static int launch_slide(const void *in, void *out, SlideGeom g, const float *lo,
     }
     const int by_lds = std::max<int>(1, (int)((size_t)kMaxLdsBytes / (lds + 512)));
     const char *env = getenv("WV_SWT_WG_PER_CU");
-    const int per_cu = env && atoi(env) > 0 ? atoi(env) : std::min(by_lds, 2048 / NT);
+    const int per_cu = env && atoi(env) > 0 ? atoi(env) : std::min(by_lds, std::max(1, MINW * 256 / (2 * NT)));
     const int64_t planes = (int64_t)g.B * g.C;
     const int64_t grid = std::min<int64_t>(planes, (int64_t)num_cu * per_cu);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, (const InT *)in, out, g, taps);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(2 * NT), lds, st, (const InT *)in, out, g, taps);
     WV_CHECK_LAUNCH("k_swt_slide");
     return WV_OK;
 }
 
-template <int L, int NLEV, int R, int TH, int NT>
+template <int L, int NLEV, int R, int TH, int NT, int MINW>
 static int slide_types(const void *in, int in_dtype, void *out, const SlideGeom &g, const float *lo, const float *hi,
                        hipStream_t st)
 {
     const bool nhwc3 = g.in_layout == WV_LAYOUT_NHWC && g.C == 3;
     if (g.in_layout != WV_LAYOUT_NCHW && !nhwc3) return 1;
-#define WV_GO(T, LAY, BF) return launch_slide<L, NLEV, R, TH, NT, T, LAY, BF>(in, out, g, lo, hi, st)
+#define WV_GO(T, LAY, BF) return launch_slide<L, NLEV, R, TH, NT, MINW, T, LAY, BF>(in, out, g, lo, hi, st)
     if (in_dtype == WV_DT_U8) {
         if (nhwc3) { if (g.out_bf16) WV_GO(uint8_t, 1, true); WV_GO(uint8_t, 1, false); }
         if (g.out_bf16) WV_GO(uint8_t, 0, true);
@@ -317,8 +392,8 @@ int swt_slide_launch(const void *in, int in_dtype, int in_layout, void *out, int
 {
     SlideGeom g{};
     g.B = B; g.C = C; g.H = H; g.W = W; g.in_layout = in_layout; g.out_bf16 = out_dtype == WV_DT_BF16;
-    if (L == 4 && n == 3) return slide_types<4, 3, 16, 16, 256>(in, in_dtype, out, g, lo, hi, st);
-    if (L == 2 && n == 1) return slide_types<2, 1, 16, 16, 256>(in, in_dtype, out, g, lo, hi, st);
+    if (L == 4 && n == 3) return slide_types<4, 3, 16, 16, 256, 4>(in, in_dtype, out, g, lo, hi, st);
+    if (L == 2 && n == 1) return slide_types<2, 1, 16, 16, 256, 4>(in, in_dtype, out, g, lo, hi, st);
     return 1;
 }
 
