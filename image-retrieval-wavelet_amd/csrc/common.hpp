@@ -37,6 +37,12 @@ void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t align_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 
+// prepared-database blob = [distance-kernel tile image][ranking-kernel column image]
+size_t dist_prepared_bytes(int64_t N, int words);
+int dist_prepare(const uint64_t *db, void *dbP, int64_t N, int words, hipStream_t st);
+size_t topk_prepared_bytes(int64_t N, int words);
+int topk_prepare(const uint64_t *db, void *dbT, int64_t N, int words, hipStream_t st);
+
 constexpr int kWave = 64;
 constexpr int kMaxLdsBytes = 160 * 1024;
 

@@ -168,6 +168,143 @@ __global__ __launch_bounds__(256) void k_hamming_dist(const uint64_t *__restrict
     }
 }
 
+// ---- prepared database: the tile image k_hamming_dist stages through LDS, stored once in HBM.
+// dbP[tile][j][t] (16 B) = bytes [t * THREAD_BYTES + 16 j, +16) of tile `tile` of the natural array, so that
+// thread t's CPT consecutive codes arrive with PER_THREAD fully coalesced 16-byte loads and no LDS pass.
+template <int WORDS>
+__global__ __launch_bounds__(256) void k_db_permute(const uint64_t *__restrict__ db, uint4 *__restrict__ dbP,
+                                                    int64_t N, int64_t tiles)
+{
+    using Cfg = DistCfg<WORDS>;
+    constexpr int PT = Cfg::THREAD_BYTES / 16;
+    const int64_t total = tiles * PT * 256;
+    const int64_t valid_bytes = N * Cfg::CODE_BYTES;
+    const uint8_t *src = reinterpret_cast<const uint8_t *>(db);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i & 255);
+        const int64_t tj = i >> 8;
+        const int j = (int)(tj % PT);
+        const int64_t tile = tj / PT;
+        const int64_t off = tile * Cfg::TILE * Cfg::CODE_BYTES + (int64_t)t * Cfg::THREAD_BYTES + 16 * j;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (off + 16 <= valid_bytes) {
+            v = *reinterpret_cast<const uint4 *>(src + off);
+        } else if (off < valid_bytes) {
+            const uint64_t lo = *reinterpret_cast<const uint64_t *>(src + off);
+            v.x = (uint32_t)lo; v.y = (uint32_t)(lo >> 32);
+        }
+        dbP[i] = v;
+    }
+}
+
+template <int WORDS, bool ALIGNED, int QCH>
+__global__ __launch_bounds__(256) void k_hamming_dist_prep(const uint64_t *__restrict__ q,
+                                                           const uint4 *__restrict__ dbP,
+                                                           uint8_t *__restrict__ dist, int64_t ld, int Q,
+                                                           int64_t N)
+{
+    using Cfg = DistCfg<WORDS>;
+    constexpr int CPT = Cfg::CPT, PT = Cfg::THREAD_BYTES / 16;
+    const int tid = threadIdx.x;
+    const int64_t n0 = (int64_t)blockIdx.x * Cfg::TILE + (int64_t)tid * CPT;
+    const int q0 = blockIdx.y * QCH;
+    uint64_t flat[PT * 2];
+    const uint4 *src = dbP + ((int64_t)blockIdx.x * PT) * 256 + tid;
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        const uint4 v = src[j * 256];
+        flat[2 * j] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        flat[2 * j + 1] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    }
+    if (n0 >= N) return;
+    const bool full = n0 + CPT <= N;
+#pragma unroll
+    for (int qq = 0; qq < QCH; ++qq) {
+        const int qi = q0 + qq;
+        if (qi >= Q) break;
+        uint64_t qw[WORDS];
+#pragma unroll
+        for (int w = 0; w < WORDS; ++w) qw[w] = q[(int64_t)qi * WORDS + w];  // uniform -> scalar loads
+        uint32_t outw[CPT / 4];
+#pragma unroll
+        for (int g4 = 0; g4 < CPT / 4; ++g4) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t d = 0;
+#pragma unroll
+                for (int w = 0; w < WORDS; ++w) d += __popcll(flat[(g4 * 4 + j) * WORDS + w] ^ qw[w]);
+                acc |= d << (8 * j);
+            }
+            outw[g4] = acc;
+        }
+        uint8_t *o = dist + (int64_t)qi * ld + n0;
+        if (ALIGNED && full) {
+            if constexpr (CPT == 16)
+                *reinterpret_cast<uint4 *>(o) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
+            else if constexpr (CPT == 8)
+                *reinterpret_cast<uint2 *>(o) = make_uint2(outw[0], outw[1]);
+            else
+                *reinterpret_cast<uint32_t *>(o) = outw[0];
+        } else {
+#pragma unroll
+            for (int c = 0; c < CPT; ++c)
+                if (n0 + c < N) o[c] = (uint8_t)(outw[c / 4] >> (8 * (c & 3)));
+        }
+    }
+}
+
+template <int WORDS>
+static int launch_dist_prep(const uint64_t *q, const void *dbP, uint8_t *dist, int64_t ld, int Q, int64_t N,
+                            hipStream_t st)
+{
+    using Cfg = DistCfg<WORDS>;
+    const int64_t tiles = ceil_div(N, Cfg::TILE);
+    constexpr int QCH = 8;
+    const int64_t qblocks = ceil_div(Q, QCH);
+    if (tiles > 0x7fffffff || qblocks > 65535) WV_FAIL(WV_ENOTSUP, "hamming_dist: grid too large");
+    const bool aligned = (ld % 16 == 0) && ((reinterpret_cast<uintptr_t>(dist) & 15) == 0);
+    dim3 grid((unsigned)tiles, (unsigned)qblocks);
+    if (aligned)
+        hipLaunchKernelGGL((k_hamming_dist_prep<WORDS, true, QCH>), grid, dim3(256), 0, st, q, (const uint4 *)dbP, dist, ld, Q, N);
+    else
+        hipLaunchKernelGGL((k_hamming_dist_prep<WORDS, false, QCH>), grid, dim3(256), 0, st, q, (const uint4 *)dbP, dist, ld, Q, N);
+    WV_CHECK_LAUNCH("k_hamming_dist_prep");
+    return WV_OK;
+}
+
+template <int WORDS>
+static int launch_permute(const uint64_t *db, void *dbP, int64_t N, hipStream_t st)
+{
+    using Cfg = DistCfg<WORDS>;
+    const int64_t tiles = ceil_div(N, Cfg::TILE);
+    const int64_t total = tiles * (Cfg::THREAD_BYTES / 16) * 256;
+    hipLaunchKernelGGL((k_db_permute<WORDS>), dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 4096)), dim3(256), 0,
+                       st, db, (uint4 *)dbP, N, tiles);
+    WV_CHECK_LAUNCH("k_db_permute");
+    return WV_OK;
+}
+
+size_t dist_prepared_bytes(int64_t N, int words)
+{
+    switch (words) {
+    case 1: return (size_t)ceil_div(N, DistCfg<1>::TILE) * DistCfg<1>::TILE * DistCfg<1>::CODE_BYTES;
+    case 2: return (size_t)ceil_div(N, DistCfg<2>::TILE) * DistCfg<2>::TILE * DistCfg<2>::CODE_BYTES;
+    case 3: return (size_t)ceil_div(N, DistCfg<3>::TILE) * DistCfg<3>::TILE * DistCfg<3>::CODE_BYTES;
+    default: return (size_t)ceil_div(N, DistCfg<4>::TILE) * DistCfg<4>::TILE * DistCfg<4>::CODE_BYTES;
+    }
+}
+
+int dist_prepare(const uint64_t *db, void *dbP, int64_t N, int words, hipStream_t st)
+{
+    switch (words) {
+    case 1: return launch_permute<1>(db, dbP, N, st);
+    case 2: return launch_permute<2>(db, dbP, N, st);
+    case 3: return launch_permute<3>(db, dbP, N, st);
+    default: return launch_permute<4>(db, dbP, N, st);
+    }
+}
+
 template <int WORDS>
 static int launch_dist(const uint64_t *q, const uint64_t *db, uint8_t *dist, int64_t ld, int Q,
                        int64_t N, hipStream_t st)
@@ -177,6 +314,7 @@ static int launch_dist(const uint64_t *q, const uint64_t *db, uint8_t *dist, int
     // enough workgroups to fill 256 CUs several times over, but keep >= 8 queries per staged tile
     int qch = 32;
     while (qch > 8 && tiles * ceil_div(Q, qch) < 2048) qch >>= 1;
+    if (const char *e = getenv("WV_DIST_QCH")) qch = std::max(1, atoi(e));
     const int64_t qblocks = ceil_div(Q, qch);
     if (tiles > 0x7fffffff || qblocks > 65535) WV_FAIL(WV_ENOTSUP, "hamming_dist: grid too large");
     const bool aligned = (ld % 16 == 0) && ((reinterpret_cast<uintptr_t>(dist) & 15) == 0);
@@ -240,5 +378,22 @@ extern "C" int wv_hamming_dist(const uint64_t *q, const uint64_t *db, uint8_t *d
     case 2: return launch_dist<2>(q, db, dist, ld_dist, Q, N, st);
     case 3: return launch_dist<3>(q, db, dist, ld_dist, Q, N, st);
     default: return launch_dist<4>(q, db, dist, ld_dist, Q, N, st);
+    }
+}
+
+extern "C" int wv_hamming_dist_prepared(const uint64_t *q, const void *prepared, uint8_t *dist, int64_t ld_dist,
+                                        int Q, int64_t N, int words, void *stream)
+{
+    WV_REQUIRE(q && prepared && dist, "hamming_dist_prepared: null buffer");
+    WV_REQUIRE(Q >= 0 && N >= 0 && ld_dist >= N, "hamming_dist_prepared: bad shape Q=%d N=%lld ld=%lld", Q,
+               (long long)N, (long long)ld_dist);
+    WV_REQUIRE(words >= 1 && words <= 4, "hamming_dist_prepared: words=%d (nbits must be <= 255)", words);
+    if (Q == 0 || N == 0) return WV_OK;
+    hipStream_t st = (hipStream_t)stream;
+    switch (words) {
+    case 1: return launch_dist_prep<1>(q, prepared, dist, ld_dist, Q, N, st);
+    case 2: return launch_dist_prep<2>(q, prepared, dist, ld_dist, Q, N, st);
+    case 3: return launch_dist_prep<3>(q, prepared, dist, ld_dist, Q, N, st);
+    default: return launch_dist_prep<4>(q, prepared, dist, ld_dist, Q, N, st);
     }
 }

@@ -28,18 +28,28 @@ struct CodeSource {
     const uint64_t *dbT;  // [C][256][WORDS]
     uint64_t qw[WORDS];
     int64_t idx_offset;
-    __device__ __forceinline__ int dist(int r, int t, int64_t) const
+    struct Raw {
+        uint64_t w[WORDS];
+    };
+    __device__ __forceinline__ Raw fetch(int r, int t, int64_t) const
     {
         const uint64_t *p = dbT + ((int64_t)r * kTopkThreads + t) * WORDS;
-        int d = 0;
+        Raw c;
         if constexpr (WORDS == 2) {
             const uint4 v = *reinterpret_cast<const uint4 *>(p);
-            d = __popcll(((uint64_t)v.x | ((uint64_t)v.y << 32)) ^ qw[0]) +
-                __popcll(((uint64_t)v.z | ((uint64_t)v.w << 32)) ^ qw[1]);
+            c.w[0] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+            c.w[1] = (uint64_t)v.z | ((uint64_t)v.w << 32);
         } else {
 #pragma unroll
-            for (int w = 0; w < WORDS; ++w) d += __popcll(p[w] ^ qw[w]);
+            for (int w = 0; w < WORDS; ++w) c.w[w] = p[w];
         }
+        return c;
+    }
+    __device__ __forceinline__ int dist(const Raw &c) const
+    {
+        int d = 0;
+#pragma unroll
+        for (int w = 0; w < WORDS; ++w) d += __popcll(c.w[w] ^ qw[w]);
         return d;
     }
     __device__ __forceinline__ int32_t id(int64_t item) const { return (int32_t)(item + idx_offset); }
@@ -51,59 +61,127 @@ struct ListSource {
     const uint8_t *dist_q;   // + (g * Q + qi) * kin + p  handled by strides below
     const int32_t *idx_q;
     int64_t shard_stride;    // Q * kin
+    int64_t n;               // G * kin (items past n read as 0 and are never counted)
     int kin;
     __device__ __forceinline__ int64_t addr(int64_t item) const
     {
         const int64_t g = item / kin;
         return g * shard_stride + (item - g * kin);
     }
-    __device__ __forceinline__ int dist(int, int, int64_t item) const { return dist_q[addr(item)]; }
+    using Raw = int;
+    __device__ __forceinline__ Raw fetch(int, int, int64_t item) const { return item < n ? dist_q[addr(item)] : 0; }
+    __device__ __forceinline__ int dist(const Raw &c) const { return c; }
     __device__ __forceinline__ int32_t id(int64_t item) const { return idx_q[addr(item)]; }
 };
 
 // RowSource: items are the entries of one stored distance-matrix row
 struct RowSource {
     const uint8_t *row;
-    __device__ __forceinline__ int dist(int, int, int64_t item) const { return row[item]; }
+    int64_t n;
+    using Raw = int;
+    __device__ __forceinline__ Raw fetch(int, int, int64_t item) const { return item < n ? row[item] : 0; }
+    __device__ __forceinline__ int dist(const Raw &c) const { return c; }
     __device__ __forceinline__ int32_t id(int64_t item) const { return (int32_t)item; }
 };
 
 // ------------------------------------------------------------------------ the ranking core
-// LDS: hist[nbins][256] u32, tot[nbins], base[nbins + 1], misc
-template <typename Source>
+// LDS: hist[nbins][256] (u32, or u16 pairs when n_items < 65536), tot[kMaxBins], base[kMaxBins + 1], misc
+//
+// U16 = true packs two threads' counters into one dword (thread t uses half t & 1 of dword t >> 1): half
+// the LDS, twice the resident workgroups.  Counters and offsets stay below 65536 because n_items does.
+template <bool U16>
+struct Hist {
+    uint32_t *h;
+    __device__ __forceinline__ uint32_t *slot(int bin, int t) const
+    {
+        return U16 ? h + bin * (kTopkThreads / 2) + (t >> 1) : h + bin * kTopkThreads + t;
+    }
+    __device__ __forceinline__ void add(int bin, int t) const
+    {
+        __hip_atomic_fetch_add(slot(bin, t), U16 ? (1u << (16 * (t & 1))) : 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ __forceinline__ uint32_t fetch_inc(int bin, int t) const
+    {
+        const uint32_t old = __hip_atomic_fetch_add(slot(bin, t), U16 ? (1u << (16 * (t & 1))) : 1u,
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return U16 ? (old >> (16 * (t & 1))) & 0xffffu : old;
+    }
+    // the four counters of threads 4*lane .. 4*lane+3 of one bin
+    __device__ __forceinline__ uint4 load4(int bin, int lane) const
+    {
+        if (U16) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(h + bin * (kTopkThreads / 2) + 2 * lane);
+            return make_uint4(v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16);
+        }
+        return *reinterpret_cast<const uint4 *>(h + bin * kTopkThreads + 4 * lane);
+    }
+    __device__ __forceinline__ void store4(int bin, int lane, uint4 o) const
+    {
+        if (U16)
+            *reinterpret_cast<uint2 *>(h + bin * (kTopkThreads / 2) + 2 * lane) = make_uint2(o.x | (o.y << 16), o.z | (o.w << 16));
+        else
+            *reinterpret_cast<uint4 *>(h + bin * kTopkThreads + 4 * lane) = o;
+    }
+    static __host__ __device__ size_t words(int nbins) { return (size_t)nbins * (U16 ? kTopkThreads / 2 : kTopkThreads); }
+};
+
+template <typename Source, bool U16>
 __device__ __forceinline__ void rank_one_query(const Source &src, int64_t n_items, int C, int nbins,
                                                int k, int32_t *__restrict__ idx_out,
                                                uint8_t *__restrict__ dist_out, uint32_t *lds)
 {
-    uint32_t *hist = lds;                              // nbins * 256
-    uint32_t *tot = hist + nbins * kTopkThreads;       // kMaxBins
+    Hist<U16> hist{lds};
+    uint32_t *tot = lds + Hist<U16>::words(nbins);     // kMaxBins
     uint32_t *base = tot + kMaxBins;                   // kMaxBins + 1
     uint32_t *misc = base + kMaxBins + 1;              // [0] = threshold bin T
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
 
-    for (int i = tid; i < nbins * kTopkThreads; i += kTopkThreads) hist[i] = 0;
+    {   // zero the table with 16-byte stores
+        uint4 *h4 = reinterpret_cast<uint4 *>(lds);
+        const int n4 = (int)(Hist<U16>::words(nbins) / 4);
+        for (int i = tid; i < n4; i += kTopkThreads) h4[i] = make_uint4(0, 0, 0, 0);
+    }
     __syncthreads();
 
-    // ---- phase 1: private-column histogram
+    // ---- phase 1: private-column histogram.  A column belongs to one thread, so the LDS adds never
+    // contend; nothing waits on them.  Distances of the next UNR items are computed while they drain.
     const int64_t first = (int64_t)tid * C;
-    for (int r = 0; r < C; ++r) {
-        const int64_t item = first + r;
-        if (item < n_items) {
-            const int d = src.dist(r, tid, item);
-            hist[d * kTopkThreads + tid] += 1;
+    constexpr int UNR = 16;
+    using Raw = typename Source::Raw;
+    const int nfull = C / UNR;
+    {
+        Raw cur[UNR], nxt[UNR];
+        if (nfull > 0) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) cur[u] = src.fetch(u, tid, first + u);
         }
+        for (int bi = 0; bi < nfull; ++bi) {
+            const int r = bi * UNR;
+            if (bi + 1 < nfull) {   // the next batch's loads are in flight while this one is counted
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) nxt[u] = src.fetch(r + UNR + u, tid, first + r + UNR + u);
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+                if (first + r + u < n_items) hist.add(src.dist(cur[u]), tid);
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) cur[u] = nxt[u];
+        }
+        for (int r = nfull * UNR; r < C; ++r)
+            if (first + r < n_items) hist.add(src.dist(src.fetch(r, tid, first + r)), tid);
     }
     __syncthreads();
 
     // ---- per-bin totals (wave w takes bins w, w+4, ...)
     for (int b = wv; b < nbins; b += kTopkThreads / 64) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(hist + b * kTopkThreads + 4 * lane);
+        const uint4 v = hist.load4(b, lane);
         const uint32_t s = wave_sum_u32(v.x + v.y + v.z + v.w);
         if (lane == 0) tot[b] = s;
     }
     __syncthreads();
 
-    // ---- exclusive scan over bins (wave 0; up to 3 bins per lane covers 192 >= 129 bins)
+    // ---- exclusive scan over bins (wave 0; up to 3 bins per lane covers 192 >= 130 bins)
     if (wv == 0) {
         uint32_t t0 = 0, t1 = 0, t2 = 0;
         const int b0 = 3 * lane;
@@ -130,7 +208,7 @@ __device__ __forceinline__ void rank_one_query(const Source &src, int64_t n_item
 
     // ---- per-bin exclusive scan over threads, plus the bin base -> starting output offsets
     for (int b = wv; b <= T; b += kTopkThreads / 64) {
-        uint4 v = *reinterpret_cast<const uint4 *>(hist + b * kTopkThreads + 4 * lane);
+        const uint4 v = hist.load4(b, lane);
         const uint32_t s = v.x + v.y + v.z + v.w;
         const uint32_t excl = wave_incl_scan_u32(s) - s + base[b];
         uint4 o;
@@ -138,18 +216,44 @@ __device__ __forceinline__ void rank_one_query(const Source &src, int64_t n_item
         o.y = excl + v.x;
         o.z = o.y + v.y;
         o.w = o.z + v.z;
-        *reinterpret_cast<uint4 *>(hist + b * kTopkThreads + 4 * lane) = o;
+        hist.store4(b, lane, o);
     }
     __syncthreads();
 
-    // ---- phase 2: stable placement of the items in bins <= T
-    for (int r = 0; r < C; ++r) {
-        const int64_t item = first + r;
-        if (item < n_items) {
-            const int d = src.dist(r, tid, item);
-            if (d <= T) {
-                const uint32_t pos = hist[d * kTopkThreads + tid]++;
-                if (pos < (uint32_t)k) idx_out[pos] = src.id(item);
+    // ---- phase 2: stable placement of the items in bins <= T (returning LDS adds, UNR in flight)
+    {
+        Raw cur[UNR], nxt[UNR];
+        if (nfull > 0) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) cur[u] = src.fetch(u, tid, first + u);
+        }
+        for (int bi = 0; bi < nfull; ++bi) {
+            const int r = bi * UNR;
+            if (bi + 1 < nfull) {
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) nxt[u] = src.fetch(r + UNR + u, tid, first + r + UNR + u);
+            }
+            uint32_t pos[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int d = src.dist(cur[u]);
+                pos[u] = 0xffffffffu;
+                if (first + r + u < n_items && d <= T) pos[u] = hist.fetch_inc(d, tid);
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+                if (pos[u] < (uint32_t)k) idx_out[pos[u]] = src.id(first + r + u);
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) cur[u] = nxt[u];
+        }
+        for (int r = nfull * UNR; r < C; ++r) {
+            const int64_t item = first + r;
+            if (item < n_items) {
+                const int d = src.dist(src.fetch(r, tid, item));
+                if (d <= T) {
+                    const uint32_t pos = hist.fetch_inc(d, tid);
+                    if (pos < (uint32_t)k) idx_out[pos] = src.id(item);
+                }
             }
         }
     }
@@ -168,10 +272,12 @@ __device__ __forceinline__ void rank_one_query(const Source &src, int64_t n_item
     }
 }
 
-static inline size_t rank_lds_bytes(int nbins)
+static inline size_t rank_lds_bytes(int nbins, bool u16)
 {
-    return ((size_t)nbins * kTopkThreads + kMaxBins + kMaxBins + 1 + 4) * sizeof(uint32_t);
+    const size_t h = (size_t)nbins * (u16 ? kTopkThreads / 2 : kTopkThreads);
+    return (h + kMaxBins + kMaxBins + 1 + 4) * sizeof(uint32_t);
 }
+static inline bool rank_u16(int64_t n_items) { return n_items < 65536; }
 
 // ------------------------------------------------------------------------ kernels
 template <int WORDS>
@@ -190,7 +296,7 @@ __global__ __launch_bounds__(kTopkThreads) void k_transpose_db(const uint64_t *_
     }
 }
 
-template <int WORDS>
+template <int WORDS, bool U16>
 __global__ __launch_bounds__(kTopkThreads) void k_hamming_topk(const uint64_t *__restrict__ q,
                                                                const uint64_t *__restrict__ dbT,
                                                                int32_t *__restrict__ idx,
@@ -205,10 +311,11 @@ __global__ __launch_bounds__(kTopkThreads) void k_hamming_topk(const uint64_t *_
     src.idx_offset = idx_offset;
 #pragma unroll
     for (int w = 0; w < WORDS; ++w) src.qw[w] = q[(int64_t)qi * WORDS + w];
-    rank_one_query(src, N, C, nbins, k, idx + (int64_t)qi * k, dist ? dist + (int64_t)qi * k : nullptr,
-                   reinterpret_cast<uint32_t *>(lds4));
+    rank_one_query<CodeSource<WORDS>, U16>(src, N, C, nbins, k, idx + (int64_t)qi * k,
+                                           dist ? dist + (int64_t)qi * k : nullptr, reinterpret_cast<uint32_t *>(lds4));
 }
 
+template <bool U16>
 __global__ __launch_bounds__(kTopkThreads) void k_topk_merge(const int32_t *__restrict__ idx_in,
                                                              const uint8_t *__restrict__ dist_in,
                                                              int G, int Q, int kin,
@@ -222,11 +329,13 @@ __global__ __launch_bounds__(kTopkThreads) void k_topk_merge(const int32_t *__re
     src.dist_q = dist_in + (int64_t)qi * kin;
     src.idx_q = idx_in + (int64_t)qi * kin;
     src.shard_stride = (int64_t)Q * kin;
+    src.n = (int64_t)G * kin;
     src.kin = kin;
-    rank_one_query(src, (int64_t)G * kin, C, nbins, k, idx_out + (int64_t)qi * k,
-                   dist_out ? dist_out + (int64_t)qi * k : nullptr, reinterpret_cast<uint32_t *>(lds4));
+    rank_one_query<ListSource, U16>(src, (int64_t)G * kin, C, nbins, k, idx_out + (int64_t)qi * k,
+                                    dist_out ? dist_out + (int64_t)qi * k : nullptr, reinterpret_cast<uint32_t *>(lds4));
 }
 
+template <bool U16>
 __global__ __launch_bounds__(kTopkThreads) void k_rank_from_dist(const uint8_t *__restrict__ dmat,
                                                                  int64_t ld, int64_t N,
                                                                  int32_t *__restrict__ idx,
@@ -237,8 +346,9 @@ __global__ __launch_bounds__(kTopkThreads) void k_rank_from_dist(const uint8_t *
     const int qi = blockIdx.x;
     RowSource src;
     src.row = dmat + (int64_t)qi * ld;
-    rank_one_query(src, N, C, nbins, k, idx + (int64_t)qi * k, dist ? dist + (int64_t)qi * k : nullptr,
-                   reinterpret_cast<uint32_t *>(lds4));
+    src.n = N;
+    rank_one_query<RowSource, U16>(src, N, C, nbins, k, idx + (int64_t)qi * k, dist ? dist + (int64_t)qi * k : nullptr,
+                                   reinterpret_cast<uint32_t *>(lds4));
 }
 
 // ------------------------------------------------------------------------ average precision
@@ -314,22 +424,53 @@ static int set_lds_attr(const void *fn, size_t bytes, const char *what)
 }
 
 template <int WORDS>
-static int launch_topk(const uint64_t *q, const uint64_t *db, int32_t *idx, uint8_t *dist, int Q,
-                       int64_t N, int nbits, int k, int64_t idx_offset, void *ws, hipStream_t st)
+static int launch_transpose(const uint64_t *db, uint64_t *dbT, int64_t N, hipStream_t st)
 {
     const int C = (int)ceil_div(N, kTopkThreads);
-    const int nbins = nbits + 1;
-    uint64_t *dbT = (uint64_t *)ws;
     const int64_t total = (int64_t)C * kTopkThreads;
     hipLaunchKernelGGL((k_transpose_db<WORDS>), dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 4096)),
                        dim3(256), 0, st, db, dbT, N, C);
-    const size_t lds = rank_lds_bytes(nbins);
-    int rc = set_lds_attr(reinterpret_cast<const void *>(k_hamming_topk<WORDS>), lds, "hamming_topk");
+    WV_CHECK_LAUNCH("k_transpose_db");
+    return WV_OK;
+}
+
+// dbT == nullptr: build the column image into `ws` first (one extra small launch per call)
+template <int WORDS>
+static int launch_topk(const uint64_t *q, const uint64_t *db, const uint64_t *dbT_ready, int32_t *idx, uint8_t *dist,
+                       int Q, int64_t N, int nbits, int k, int64_t idx_offset, void *ws, hipStream_t st)
+{
+    const int C = (int)ceil_div(N, kTopkThreads);
+    const int nbins = nbits + 1;
+    const uint64_t *dbT = dbT_ready;
+    if (!dbT) {
+        int rc0 = launch_transpose<WORDS>(db, (uint64_t *)ws, N, st);
+        if (rc0) return rc0;
+        dbT = (const uint64_t *)ws;
+    }
+    const bool u16 = rank_u16(N);
+    const size_t lds = rank_lds_bytes(nbins, u16);
+    int rc = set_lds_attr(u16 ? reinterpret_cast<const void *>(k_hamming_topk<WORDS, true>)
+                              : reinterpret_cast<const void *>(k_hamming_topk<WORDS, false>), lds, "hamming_topk");
     if (rc) return rc;
-    hipLaunchKernelGGL((k_hamming_topk<WORDS>), dim3(Q), dim3(kTopkThreads), lds, st, q, dbT, idx, dist,
-                       N, C, nbins, k, idx_offset);
+    if (u16)
+        hipLaunchKernelGGL((k_hamming_topk<WORDS, true>), dim3(Q), dim3(kTopkThreads), lds, st, q, dbT, idx, dist,
+                           N, C, nbins, k, idx_offset);
+    else
+        hipLaunchKernelGGL((k_hamming_topk<WORDS, false>), dim3(Q), dim3(kTopkThreads), lds, st, q, dbT, idx, dist,
+                           N, C, nbins, k, idx_offset);
     WV_CHECK_LAUNCH("k_hamming_topk");
     return WV_OK;
+}
+
+size_t topk_prepared_bytes(int64_t N, int words)
+{
+    return (size_t)ceil_div(N, kTopkThreads) * kTopkThreads * words * sizeof(uint64_t);
+}
+
+int topk_prepare(const uint64_t *db, void *dbT, int64_t N, int words, hipStream_t st)
+{
+    if (words == 1) return launch_transpose<1>(db, (uint64_t *)dbT, N, st);
+    return launch_transpose<2>(db, (uint64_t *)dbT, N, st);
 }
 
 }  // namespace wv
@@ -359,8 +500,45 @@ extern "C" int wv_hamming_topk(const uint64_t *q, const uint64_t *db, int32_t *i
         WV_FAIL(WV_ENOMEM, "hamming_topk: workspace %zu < %zu bytes", workspace_bytes, need);
     if (Q == 0) return WV_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (words == 1) return launch_topk<1>(q, db, idx, dist, Q, N, nbits, k, idx_offset, workspace, st);
-    return launch_topk<2>(q, db, idx, dist, Q, N, nbits, k, idx_offset, workspace, st);
+    if (words == 1) return launch_topk<1>(q, db, nullptr, idx, dist, Q, N, nbits, k, idx_offset, workspace, st);
+    return launch_topk<2>(q, db, nullptr, idx, dist, Q, N, nbits, k, idx_offset, workspace, st);
+}
+
+extern "C" size_t wv_db_prepared_bytes(int64_t N, int words)
+{
+    if (N <= 0 || words < 1 || words > 4) return 0;
+    return align_up((int64_t)dist_prepared_bytes(N, words), 256) + (words <= 2 ? topk_prepared_bytes(N, words) : 0);
+}
+
+extern "C" int wv_db_prepare(const uint64_t *db, int64_t N, int words, void *prepared, size_t prepared_bytes,
+                             void *stream)
+{
+    WV_REQUIRE(db && prepared, "db_prepare: null buffer");
+    WV_REQUIRE(N >= 1 && words >= 1 && words <= 4, "db_prepare: bad shape N=%lld words=%d", (long long)N, words);
+    const size_t need = wv_db_prepared_bytes(N, words);
+    if (prepared_bytes < need) WV_FAIL(WV_ENOMEM, "db_prepare: buffer %zu < %zu bytes", prepared_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = dist_prepare(db, prepared, N, words, st);
+    if (rc) return rc;
+    if (words <= 2)
+        rc = topk_prepare(db, (char *)prepared + align_up((int64_t)dist_prepared_bytes(N, words), 256), N, words, st);
+    return rc;
+}
+
+extern "C" int wv_hamming_topk_prepared(const uint64_t *q, const void *prepared, int32_t *idx, uint8_t *dist, int Q,
+                                        int64_t N, int nbits, int k, int64_t idx_offset, void *stream)
+{
+    WV_REQUIRE(q && prepared && idx, "hamming_topk_prepared: null buffer");
+    WV_REQUIRE(Q >= 0 && N >= 1, "hamming_topk_prepared: bad shape Q=%d N=%lld", Q, (long long)N);
+    WV_REQUIRE(nbits >= 1 && nbits <= 128, "hamming_topk_prepared: nbits=%d (supported: 1..128)", nbits);
+    WV_REQUIRE(k >= 1 && k <= N, "hamming_topk_prepared: k=%d must be in [1, N=%lld]", k, (long long)N);
+    WV_REQUIRE(N + idx_offset <= 0x7fffffffLL && idx_offset >= 0, "hamming_topk_prepared: indices exceed int32");
+    if (Q == 0) return WV_OK;
+    const int words = (nbits + 63) / 64;
+    const uint64_t *dbT = (const uint64_t *)((const char *)prepared + align_up((int64_t)dist_prepared_bytes(N, words), 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (words == 1) return launch_topk<1>(q, nullptr, dbT, idx, dist, Q, N, nbits, k, idx_offset, nullptr, st);
+    return launch_topk<2>(q, nullptr, dbT, idx, dist, Q, N, nbits, k, idx_offset, nullptr, st);
 }
 
 extern "C" int wv_topk_merge(const int32_t *idx_in, const uint8_t *dist_in, int G, int Q, int kin,
@@ -374,11 +552,17 @@ extern "C" int wv_topk_merge(const int32_t *idx_in, const uint8_t *dist_in, int 
     const int64_t items = (int64_t)G * kin;
     const int C = (int)ceil_div(items, kTopkThreads);
     const int nbins = nbits + 2;  // dist = nbits + 1 marks padding entries: they rank after every real one
-    const size_t lds = rank_lds_bytes(nbins);
-    int rc = set_lds_attr(reinterpret_cast<const void *>(k_topk_merge), lds, "topk_merge");
+    const bool u16 = rank_u16(items);
+    const size_t lds = rank_lds_bytes(nbins, u16);
+    int rc = set_lds_attr(u16 ? reinterpret_cast<const void *>(k_topk_merge<true>)
+                              : reinterpret_cast<const void *>(k_topk_merge<false>), lds, "topk_merge");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_topk_merge, dim3(Q), dim3(kTopkThreads), lds, (hipStream_t)stream, idx_in,
-                       dist_in, G, Q, kin, idx_out, dist_out, k, C, nbins);
+    if (u16)
+        hipLaunchKernelGGL(k_topk_merge<true>, dim3(Q), dim3(kTopkThreads), lds, (hipStream_t)stream, idx_in,
+                           dist_in, G, Q, kin, idx_out, dist_out, k, C, nbins);
+    else
+        hipLaunchKernelGGL(k_topk_merge<false>, dim3(Q), dim3(kTopkThreads), lds, (hipStream_t)stream, idx_in,
+                           dist_in, G, Q, kin, idx_out, dist_out, k, C, nbins);
     WV_CHECK_LAUNCH("k_topk_merge");
     return WV_OK;
 }
@@ -393,11 +577,17 @@ extern "C" int wv_rank_from_dist(const uint8_t *dist_matrix, int64_t ld_dist, in
     if (Q == 0) return WV_OK;
     const int C = (int)ceil_div(N, kTopkThreads);
     const int nbins = nbits + 1;
-    const size_t lds = rank_lds_bytes(nbins);
-    int rc = set_lds_attr(reinterpret_cast<const void *>(k_rank_from_dist), lds, "rank_from_dist");
+    const bool u16 = rank_u16(N);
+    const size_t lds = rank_lds_bytes(nbins, u16);
+    int rc = set_lds_attr(u16 ? reinterpret_cast<const void *>(k_rank_from_dist<true>)
+                              : reinterpret_cast<const void *>(k_rank_from_dist<false>), lds, "rank_from_dist");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_rank_from_dist, dim3(Q), dim3(kTopkThreads), lds, (hipStream_t)stream,
-                       dist_matrix, ld_dist, N, idx, dist, k, C, nbins);
+    if (u16)
+        hipLaunchKernelGGL(k_rank_from_dist<true>, dim3(Q), dim3(kTopkThreads), lds, (hipStream_t)stream,
+                           dist_matrix, ld_dist, N, idx, dist, k, C, nbins);
+    else
+        hipLaunchKernelGGL(k_rank_from_dist<false>, dim3(Q), dim3(kTopkThreads), lds, (hipStream_t)stream,
+                           dist_matrix, ld_dist, N, idx, dist, k, C, nbins);
     WV_CHECK_LAUNCH("k_rank_from_dist");
     return WV_OK;
 }

@@ -54,6 +54,10 @@ SIGNATURES = {
     "wv_hamming_dist": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _i, _vp]),
     "wv_hamming_topk_workspace_bytes": (_sz, [_i, _i64, _i, _i]),
     "wv_hamming_topk": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i64, _vp, _sz, _vp]),
+    "wv_db_prepared_bytes": (_sz, [_i64, _i]),
+    "wv_db_prepare": (_i, [_vp, _i64, _i, _vp, _sz, _vp]),
+    "wv_hamming_dist_prepared": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _i, _vp]),
+    "wv_hamming_topk_prepared": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i64, _vp]),
     "wv_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
     "wv_rank_from_dist": (_i, [_vp, _i64, _i, _i64, _i, _vp, _vp, _i, _vp]),
     "wv_map_at_k": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),

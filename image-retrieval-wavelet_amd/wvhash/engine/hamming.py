@@ -65,19 +65,53 @@ def bit_counts(packed, nbits):
     return counts
 
 
-def hamming_dist(q_packed, db_packed):
-    """-> uint8 [Q, N] view (row pitch padded to 64 bytes so every row store is 16-B aligned)."""
+class PreparedDB:
+    """A packed database laid out once for the kernels (wv_db_prepare): what index.add() is to the
+    reference's faiss path (get_knn.py:54), except that it is built once per database, not per call."""
+
+    def __init__(self, db_packed, nbits=None):
+        lib = _lib.require_gpu()
+        if db_packed.dim() != 2 or db_packed.dtype != torch.int64:
+            raise ValueError("PreparedDB: expected packed int64 codes [N, words] (see pack_codes)")
+        self.packed = db_packed.contiguous()
+        self.N, self.words = self.packed.shape
+        self.nbits = nbits if nbits is not None else self.words * 64
+        nbytes = lib.wv_db_prepared_bytes(self.N, self.words)
+        self.blob = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.packed.device)
+        if self.N:
+            with torch.cuda.device(self.packed.device):
+                rc = lib.wv_db_prepare(_lib.ptr(self.packed), self.N, self.words, _lib.ptr(self.blob),
+                                       ctypes.c_size_t(nbytes), _lib.stream_ptr())
+                _lib.check(rc, "wv_db_prepare")
+
+    @property
+    def shape(self):
+        return self.packed.shape
+
+    @property
+    def device(self):
+        return self.packed.device
+
+
+def hamming_dist(q_packed, db):
+    """-> uint8 [Q, N] view (row pitch padded to 64 bytes so every row store is 16-B aligned).
+    `db`: packed int64 codes [N, words] or a PreparedDB."""
     lib = _lib.require_gpu()
     Q, words = q_packed.shape
-    N = db_packed.shape[0]
-    if db_packed.shape[1] != words:
+    prepared = isinstance(db, PreparedDB)
+    N, dwords = (db.N, db.words) if prepared else db.shape
+    if dwords != words:
         raise ValueError("hamming_dist: query and database code widths differ")
     ld = (N + 63) // 64 * 64
     buf = torch.empty((Q, ld), dtype=torch.uint8, device=q_packed.device)
     if Q and N:
         with torch.cuda.device(q_packed.device):
-            rc = lib.wv_hamming_dist(_lib.ptr(q_packed), _lib.ptr(db_packed), _lib.ptr(buf), ld, Q, N, words,
-                                     _lib.stream_ptr())
+            if prepared:
+                rc = lib.wv_hamming_dist_prepared(_lib.ptr(q_packed), _lib.ptr(db.blob), _lib.ptr(buf), ld, Q, N,
+                                                  words, _lib.stream_ptr())
+            else:
+                rc = lib.wv_hamming_dist(_lib.ptr(q_packed), _lib.ptr(db), _lib.ptr(buf), ld, Q, N, words,
+                                         _lib.stream_ptr())
             _lib.check(rc, "wv_hamming_dist")
     return buf[:, :N]
 
@@ -94,23 +128,30 @@ class TopkWorkspace:
         return self.buf
 
 
-def hamming_topk(q_packed, db_packed, nbits, k, idx_offset=0, workspace=None, want_dist=True):
+def hamming_topk(q_packed, db, nbits, k, idx_offset=0, workspace=None, want_dist=True):
     """k nearest database rows per query, ascending (distance, index).
+    `db`: packed int64 codes [N, words] or a PreparedDB.
     -> (idx int32 [Q,k], dist uint8 [Q,k] or None)."""
     lib = _lib.require_gpu()
     Q, words = q_packed.shape
-    N = db_packed.shape[0]
-    if db_packed.shape[1] != words or words != _words(nbits):
+    prepared = isinstance(db, PreparedDB)
+    N, dwords = (db.N, db.words) if prepared else db.shape
+    if dwords != words or words != _words(nbits):
         raise ValueError("hamming_topk: code widths do not match nbits")
     dev = q_packed.device
     idx = torch.empty((Q, k), dtype=torch.int32, device=dev)
     dist = torch.empty((Q, k), dtype=torch.uint8, device=dev) if want_dist else None
-    ws_bytes = lib.wv_hamming_topk_workspace_bytes(Q, N, words, k)
-    ws = (workspace or TopkWorkspace()).get(ws_bytes, dev)
     with torch.cuda.device(dev):
-        rc = lib.wv_hamming_topk(_lib.ptr(q_packed), _lib.ptr(db_packed), _lib.ptr(idx), _lib.ptr(dist), Q, N,
-                                 nbits, k, idx_offset, _lib.ptr(ws), ctypes.c_size_t(ws.numel()),
-                                 _lib.stream_ptr())
+        if prepared and words <= 2:
+            rc = lib.wv_hamming_topk_prepared(_lib.ptr(q_packed), _lib.ptr(db.blob), _lib.ptr(idx), _lib.ptr(dist),
+                                              Q, N, nbits, k, idx_offset, _lib.stream_ptr())
+        else:
+            db_packed = db.packed if prepared else db
+            ws_bytes = lib.wv_hamming_topk_workspace_bytes(Q, N, words, k)
+            ws = (workspace or TopkWorkspace()).get(ws_bytes, dev)
+            rc = lib.wv_hamming_topk(_lib.ptr(q_packed), _lib.ptr(db_packed), _lib.ptr(idx), _lib.ptr(dist), Q, N,
+                                     nbits, k, idx_offset, _lib.ptr(ws), ctypes.c_size_t(ws.numel()),
+                                     _lib.stream_ptr())
         _lib.check(rc, "wv_hamming_topk")
     return idx, dist
 

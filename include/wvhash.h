@@ -107,6 +107,21 @@ int wv_hamming_topk(const uint64_t *q, const uint64_t *db, int32_t *idx, uint8_t
                     int64_t N, int nbits, int k, int64_t idx_offset, void *workspace,
                     size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Prepared database.  The reference rebuilds a faiss index on every call (index.add, get_knn.py:54);
+ * here the per-database work is explicit: wv_db_prepare lays the packed codes out once in the two
+ * images the kernels read with fully coalesced loads (distance tile image + ranking column image),
+ * and the *_prepared entry points skip the per-call re-layout.  Results are identical to the
+ * plain entry points.  `prepared` is caller-owned device memory of wv_db_prepared_bytes() bytes.
+ * ------------------------------------------------------------------------------------------ */
+size_t wv_db_prepared_bytes(int64_t N, int words);
+int wv_db_prepare(const uint64_t *db, int64_t N, int words, void *prepared, size_t prepared_bytes,
+                  void *stream);
+int wv_hamming_dist_prepared(const uint64_t *q, const void *prepared, uint8_t *dist, int64_t ld_dist,
+                             int Q, int64_t N, int words, void *stream);
+int wv_hamming_topk_prepared(const uint64_t *q, const void *prepared, int32_t *idx, uint8_t *dist, int Q,
+                             int64_t N, int nbits, int k, int64_t idx_offset, void *stream);
+
 /* Merge of G per-shard top-k lists (gathered with one all-gather) into the global top-k.
  * Replaces the host-side shard merge inside faiss.index_cpu_to_all_gpus(shards=True)
  *   (get_knn.py:41-44).  Lists must come from contiguous row shards in rank order, so that

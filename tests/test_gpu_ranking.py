@@ -63,6 +63,10 @@ def test_seeded_sizes_against_oracle(Q, N, nbits, k):
     ref_idx, ref_dk = ranking.hamming_topk_stable(q, r, k)
     assert torch.equal(idx.cpu().long(), ref_idx)
     assert torch.equal(dk.cpu().long(), ref_dk)
+    prep = H.PreparedDB(rp, nbits)                      # prepared layouts: identical results
+    assert torch.equal(H.hamming_dist(qp, prep), d)
+    pi, pd = H.hamming_topk(qp, prep, nbits, k)
+    assert torch.equal(pi, idx) and torch.equal(pd, dk)
 
 
 def test_structured_codes_map_parity_c1_shape():
