@@ -1,0 +1,82 @@
+"""End-to-end evaluate() / evaluate_multi_k() on the GPU with a synthetic hashing dataset and a stub
+backbone: same call shape and return shape as the reference's main/engine/evaluate.py:143-245, metrics
+checked against the oracle on the codes the model produced."""
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+from torch.utils.data import Dataset
+
+from oracle import ranking
+from wvhash import synth
+from wvhash.engine import evaluate, evaluate_multi_k
+from wvhash.models import SharedDinoHashing
+from wvhash.models.vit import tiny_vit
+from wvhash.transforms import SWTTransform
+
+pytestmark = pytest.mark.gpu
+
+
+class SynthHashing(Dataset):
+    """{"image","label","path"} items like MIRFlickrHashing.__getitem__ (flikr_coco.py:52-63)."""
+
+    def __init__(self, n, seed, transform):
+        self.imgs = synth.natural_images(n, 224, 224, seed=seed)
+        self.labels = synth.multi_hot_labels(n, 38, 0.10, seed)
+        self.transform = transform
+
+    def __len__(self):
+        return len(self.imgs)
+
+    def __getitem__(self, i):
+        return {"image": self.transform(Image.fromarray(self.imgs[i])), "label": self.labels[i], "path": str(i)}
+
+
+@pytest.fixture(scope="module")
+def setup():
+    torch.manual_seed(0)
+    fusion = {"type": "cross_attention_advanced", "output_dim": 384, "num_heads": 8, "num_queries": 4,
+              "sub_band_dropout_p": 0, "ortho_weight": 0.1}
+    net = SharedDinoHashing({"name": "dinov2_vits14", "frozen": True}, fusion, {"nbits": 64}, backbone=tiny_vit())
+    net.hash_fc.weight.data.mul_(50)                      # spread the logits away from 0
+    net = net.cuda().eval().set_wavelet(level=1, wavelet="haar")
+    tf = SWTTransform(level=1, wavelet="haar", defer=True)   # workers only size the image; SWT runs batched
+    return net, {"test": SynthHashing(24, 1, tf), "gallery": SynthHashing(160, 2, tf)}
+
+
+def oracle_metrics(net, dts, k):
+    with torch.no_grad():
+        enc = lambda d: net(torch.stack([d[i]["image"] for i in range(len(d))]).cuda()).cpu()
+        q, r = enc(dts["test"]), enc(dts["gallery"])
+    assert set(q.unique().tolist()) <= {-1.0, 1.0}
+    return ranking.calculate_maphashing(q, dts["test"].labels, r, dts["gallery"].labels, k, stable=True), \
+        ranking.calculate_bit_balance(r)
+
+
+def test_evaluate_return_shape_and_values(setup):
+    net, dts = setup
+    rng_before = torch.get_rng_state()
+    m = evaluate(net, test_dataset=dts, epoch=7, batch_size=16, num_workers=0, k=50, distance_metric="hamming",
+                 exclude=["mean_reciprocal_rank", "precision_at_1", "r_precision", "rpr", "pr", "pr_rc"])
+    assert torch.equal(rng_before, torch.get_rng_state())
+    assert set(m) == {"test"} and m["test"]["epoch"] == "7"
+    for key in ("maphashing_level0", "map_level0", "bit_balance_level0", "worst_bit_balance_level0"):
+        assert key in m["test"], key
+    map_ref, bb_ref = oracle_metrics(net, dts, 50)
+    assert abs(m["test"]["maphashing_level0"] - map_ref) < 1e-6
+    assert abs(m["test"]["bit_balance_level0"] - bb_ref) < 1e-6
+
+
+def test_evaluate_multi_k_embeds_once(setup):
+    net, dts = setup
+    calls = {"n": 0}
+    h = net.fusion_head.register_forward_hook(lambda *a: calls.__setitem__("n", calls["n"] + 1))
+    res = evaluate_multi_k(net, test_dataset=dts, epoch=3, k_list=(20, 160), batch_size=32, num_workers=0,
+                           distance_metric="hamming", exclude=["map", "precision_at_1"])
+    h.remove()
+    assert calls["n"] == 1 + 5                               # 24 queries / 32 + 160 gallery / 32: one sweep only
+    assert set(res) == {20, 160}
+    for k in (20, 160):
+        ref, _ = oracle_metrics(net, dts, k)
+        assert abs(res[k]["test"]["maphashing_level0"] - ref) < 1e-6
+        assert "map_level0" not in res[k]["test"]
