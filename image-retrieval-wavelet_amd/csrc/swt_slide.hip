@@ -16,6 +16,7 @@
 #include "common.hpp"
 #include "swt_fused.hpp"
 #include <type_traits>
+#include <vector>
 
 namespace wv {
 
@@ -31,6 +32,7 @@ struct SlideGeom {
     int nrun;       // runs per row = ceil(W / R)
     int in_layout;
     int out_bf16;
+    unsigned long long *stamps;   // diagnostic build only
 };
 
 template <int L, int NLEV, int NOUT>
@@ -214,10 +216,14 @@ __device__ __forceinline__ float4 s_convert4(const SRaw<InT, LAYOUT> &r, int c)
 // One barrier per chunk hands the buffers over.  Each role needs well under 128 VGPRs, so two
 // workgroups (16 waves) fit a CU and the two halves of every SIMD pair overlap load latency,
 // row arithmetic, column arithmetic and the output stream.
-template <int L, int NLEV, int R, int TH, int NH, int MINW, typename InT, int LAYOUT, bool BF16>
+// STAMP = true is a diagnostic build (WV_SWT_STAMPS=1): per-wave s_memtime totals of the three segments of
+// each role go to g.stamps (never read by the kernel, never part of an output).
+#define WV_STAMP(var) do { if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } } while (0)
+template <int L, int NLEV, int R, int TH, int NH, int MINW, typename InT, int LAYOUT, bool BF16, bool STAMP = false>
 __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restrict__ in, void *__restrict__ out,
                                                             SlideGeom g, STaps<L> taps)
 {
+    uint64_t st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, acc_a = 0, acc_b = 0, acc_c = 0, acc_d = 0, acc_e = 0;
     using CH = SChain<L, NLEV, R>;
     using Raw = SRaw<InT, LAYOUT>;
     using OutT = typename std::conditional<BF16, __hip_bfloat16, float>::type;
@@ -256,6 +262,7 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
             };
             if (active) fetch(0);
             for (int k = 0; k < nchunks; ++k) {
+                WV_STAMP(st0);
                 if (active) {
                     float v[NG * 4];
 #pragma unroll
@@ -263,15 +270,21 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
                         const float4 p4 = s_convert4<InT, LAYOUT>(raw[q], c);
                         v[4 * q + 0] = p4.x; v[4 * q + 1] = p4.y; v[4 * q + 2] = p4.z; v[4 * q + 3] = p4.w;
                     }
+                    WV_STAMP(st1);
                     if (k + 1 < nchunks) fetch(k + 1);     // next chunk's pixels fly during the arithmetic
+                    WV_STAMP(st4);
                     // in-place cascade on v[off ..): element i of the run lives at v[i + off]
                     constexpr int off = HBa - HB;
                     float w[CH::NIN];
 #pragma unroll
                     for (int i = 0; i < CH::NIN; ++i) w[i] = v[i + off];
                     CH::template lower<1>(w, taps.lo);
-                    float *plo = ring + (k & 1) * buf_sz + rr * P + j * R;
+                    WV_STAMP(st5);
+                    // LDS row layout is permuted so that consecutive lanes (= consecutive runs j) write
+                    // consecutive 16-byte slots: column x = j*R + 4*q4 + e lives at q4*(4*nrun) + 4*j + e
+                    float *plo = ring + (k & 1) * buf_sz + rr * P + 4 * j;
                     float *phi = plo + plane_sz;
+                    const int qstride = 4 * g.nrun;
 #pragma unroll
                     for (int q4 = 0; q4 < R / 4; ++q4) {
                         float4 lo4, hi4;
@@ -279,17 +292,22 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
                         lo4.y = CH::last(w, taps.lo, 4 * q4 + 1); hi4.y = CH::last(w, taps.hi, 4 * q4 + 1);
                         lo4.z = CH::last(w, taps.lo, 4 * q4 + 2); hi4.z = CH::last(w, taps.hi, 4 * q4 + 2);
                         lo4.w = CH::last(w, taps.lo, 4 * q4 + 3); hi4.w = CH::last(w, taps.hi, 4 * q4 + 3);
-                        *reinterpret_cast<float4 *>(plo + 4 * q4) = lo4;
-                        *reinterpret_cast<float4 *>(phi + 4 * q4) = hi4;
+                        *reinterpret_cast<float4 *>(plo + q4 * qstride) = lo4;
+                        *reinterpret_cast<float4 *>(phi + q4 * qstride) = hi4;
                     }
                 }
+                WV_STAMP(st2);
                 __syncthreads();   // buffer k & 1 is full; buffer (k+1) & 1 was drained before this barrier
+                WV_STAMP(st3);
+                if constexpr (STAMP) { acc_a += st1 - st0; acc_b += st2 - st5; acc_c += st3 - st2; acc_d += st4 - st1; acc_e += st5 - st4; }
             }
             __syncthreads();       // pairs with the consumer's last barrier of the plane
         }
     } else {
         // ------------------------------------------------------------------ consumer: pass V
         const bool active = t < W;
+        // this column's slot in the permuted LDS row (see pass H)
+        const int tp = ((t % R) / 4) * (4 * g.nrun) + (t / R) * 4 + (t & 3);
         for (int pc = blockIdx.x; pc < nplanes; pc += gridDim.x) {
             OutT *oplane = reinterpret_cast<OutT *>(out) + (size_t)pc * 4 * band;
             float tail[2][HALO];
@@ -298,14 +316,16 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
             __syncthreads();       // chunk 0 produced
             for (int k = 0; k < nchunks; ++k) {
                 const int y0 = k * TH - HALO;              // first output row this chunk emits (uniform)
+                WV_STAMP(st0);
                 if (active) {
 #pragma unroll
                     for (int pl = 0; pl < 2; ++pl) {
-                        const float *col = ring + (k & 1) * buf_sz + pl * plane_sz + t;
+                        const float *col = ring + (k & 1) * buf_sz + pl * plane_sz + tp;
                         float cur[TH];
 #pragma unroll
                         for (int i = 0; i < TH; ++i) cur[i] = col[i * P];
                         VStep<L, NLEV, TH>::template lower<1>(cur, tail[pl], taps.lo);
+                        if (pl == 0) WV_STAMP(st1);
                         if (y0 + TH <= 0) {               // nothing to emit yet: only advance the state
                             VStep<L, NLEV, TH>::prime_last(cur, tail[pl]);
                         } else {
@@ -321,8 +341,17 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
                         }
                     }
                 }
+                WV_STAMP(st2);
                 __syncthreads();   // buffer k & 1 drained, buffer (k+1) & 1 full
+                WV_STAMP(st3);
+                if constexpr (STAMP) { acc_a += st1 - st0; acc_b += st2 - st1; acc_c += st3 - st2; }
             }
+        }
+    }
+    if constexpr (STAMP) {
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long *o = g.stamps + ((size_t)blockIdx.x * (2 * NH / 64) + threadIdx.x / 64) * 8;
+            o[0] = acc_a; o[1] = acc_b; o[2] = acc_c; o[3] = is_h; o[4] = acc_d; o[5] = acc_e;
         }
     }
 }
@@ -359,6 +388,32 @@ static int launch_slide(const void *in, void *out, SlideGeom g, const float *lo,
     const int per_cu = env && atoi(env) > 0 ? atoi(env) : std::min(by_lds, std::max(1, MINW * 256 / (2 * NT)));
     const int64_t planes = (int64_t)g.B * g.C;
     const int64_t grid = std::min<int64_t>(planes, (int64_t)num_cu * per_cu);
+    if (getenv("WV_SWT_STAMPS")) {   // diagnostic build: run once, print where each role's cycles go
+        auto kstamp = k_swt_slide<L, NLEV, R, TH, NT, MINW, InT, LAYOUT, BF16, true>;
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kstamp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const size_t nw = (size_t)grid * (2 * NT / 64);
+        unsigned long long *dbuf = nullptr;
+        if (hipMalloc(&dbuf, nw * 8 * sizeof(unsigned long long)) != hipSuccess) WV_FAIL(WV_EHIP, "stamps: hipMalloc");
+        g.stamps = dbuf;
+        hipLaunchKernelGGL(kstamp, dim3((unsigned)grid), dim3(2 * NT), lds, st, (const InT *)in, out, g, taps);
+        std::vector<unsigned long long> hbuf(nw * 8, 0);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(hbuf.data(), dbuf, nw * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        (void)hipFree(dbuf);
+        double a[2][6] = {{0}, {0}};
+        size_t cnt[2] = {0, 0};
+        for (size_t i = 0; i < nw; ++i) {
+            const int role = (int)hbuf[8 * i + 3];
+            for (int c = 0; c < 6; ++c) a[role][c] += (double)hbuf[8 * i + c];
+            cnt[role]++;
+        }
+        fprintf(stderr, "[swt stamps] V waves=%zu: LDS read+lower(pl0) %.0f | rest(last+stores, pl1) %.0f | barrier %.0f\n", cnt[0],
+                a[0][0] / cnt[0], a[0][1] / cnt[0], a[0][2] / cnt[0]);
+        fprintf(stderr, "[swt stamps] H waves=%zu: wait loads+convert %.0f | issue next loads %.0f | lower levels %.0f | last level+LDS write %.0f | barrier %.0f\n",
+                cnt[1], a[1][0] / cnt[1], a[1][4] / cnt[1], a[1][5] / cnt[1], a[1][1] / cnt[1], a[1][2] / cnt[1]);
+        return WV_OK;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(2 * NT), lds, st, (const InT *)in, out, g, taps);
     WV_CHECK_LAUNCH("k_swt_slide");
     return WV_OK;
