@@ -16,6 +16,7 @@
 namespace wv {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;   // native vector: arrays of it stay in registers
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_ADD_ROW = 2, EPI_ADD_BCAST = 3 };
 
@@ -76,6 +77,119 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const float *__restrict__ A, co
                 const int64_t row = i0 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (row >= M) continue;
                 float v = acc[a][b][e] + bs;
+                if (EPI == EPI_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                if (EPI == EPI_ADD_ROW) v += R[row * N + col];
+                if (EPI == EPI_ADD_BCAST) v += R[(row % rmod) * N + col];
+                C[row * N + col] = v;
+            }
+        }
+}
+
+// LDS-tiled variant for K % 32 == 0: block tile BM x BN, K step 32, two LDS stages (global loads of step
+// i+1 are in flight while step i feeds the matrix cores).  4 waves as 2 x 2; wave tile (BM/2) x (BN/2) in
+// 32 x 32 MFMA blocks.  Rows are padded to 36 floats: lanes = rows then hit 16 distinct 4-bank groups per
+// ds_read_b128 (conflict-free).  Same k <-> (step, lane half) bijection as k_gemm_nt.
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm_lds(const float *__restrict__ A, const float *__restrict__ W,
+                                                  const float *__restrict__ bias, const float *__restrict__ R,
+                                                  int rmod, float *__restrict__ C, int M, int N, int K)
+{
+    constexpr int BK = 32, LDP = BK + 4;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int A4 = BM * (BK / 4) / 256, B4 = BN * (BK / 4) / 256;   // float4 loads per thread per stage
+    extern __shared__ float4 gsm4[];
+    float *sm = reinterpret_cast<float *>(gsm4);
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+    const int wm = (wv >> 1) * (BM / 2), wn = (wv & 1) * (BN / 2);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    // global -> register staging: chunk i of this thread = float4 (row = (i*256 + tid) / 8, col4 = (..) % 8).
+    // (Plain macros, not lambdas: arrays captured by reference end up in scratch memory.)
+    f32x4 ra[A4], rb[B4];
+    const float *ga[A4], *gb[B4];
+    int so_a[A4], so_b[B4];
+#pragma unroll
+    for (int i = 0; i < A4; ++i) {
+        const int ch = i * 256 + tid, row = ch >> 3, c4 = ch & 7;
+        ga[i] = A + min(m0 + row, (int64_t)M - 1) * K + 4 * c4;
+        so_a[i] = row * LDP + 4 * c4;
+    }
+#pragma unroll
+    for (int i = 0; i < B4; ++i) {
+        const int ch = i * 256 + tid, row = ch >> 3, c4 = ch & 7;
+        gb[i] = W + min(n0 + row, (int64_t)N - 1) * K + 4 * c4;
+        so_b[i] = BM * LDP + row * LDP + 4 * c4;
+    }
+    constexpr int STAGE = (BM + BN) * LDP;   // floats per stage: [A tile | B tile]
+#pragma unroll
+    for (int i = 0; i < A4; ++i) ra[i] = *reinterpret_cast<const f32x4 *>(ga[i]);
+#pragma unroll
+    for (int i = 0; i < B4; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(gb[i]);
+#pragma unroll
+    for (int i = 0; i < A4; ++i) *reinterpret_cast<f32x4 *>(sm + so_a[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B4; ++i) *reinterpret_cast<f32x4 *>(sm + so_b[i]) = rb[i];
+    __syncthreads();
+    const int nk = K / BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        float *cur = sm + (kt & 1) * STAGE;
+        float *nxt = sm + ((kt & 1) ^ 1) * STAGE;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            const int k0 = (kt + 1) * BK;
+#pragma unroll
+            for (int i = 0; i < A4; ++i) ra[i] = *reinterpret_cast<const f32x4 *>(ga[i] + k0);
+#pragma unroll
+            for (int i = 0; i < B4; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(gb[i] + k0);
+        }
+        const float *as = cur + (wm + r) * LDP + 4 * h;
+        const float *bs = cur + BM * LDP + (wn + r) * LDP + 4 * h;
+#pragma unroll
+        for (int c = 0; c < BK / 8; ++c) {
+            f32x4 av[TM], bv[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) av[a] = *reinterpret_cast<const f32x4 *>(as + a * 32 * LDP + 8 * c);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bv[b] = *reinterpret_cast<const f32x4 *>(bs + b * 32 * LDP + 8 * c);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].x, bv[b].x, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].y, bv[b].y, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].z, bv[b].z, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].w, bv[b].w, acc[a][b], 0, 0, 0);
+                }
+        }
+        if (more) {   // the other stage was last read before the previous barrier
+#pragma unroll
+            for (int i = 0; i < A4; ++i) *reinterpret_cast<f32x4 *>(nxt + so_a[i]) = ra[i];
+#pragma unroll
+            for (int i = 0; i < B4; ++i) *reinterpret_cast<f32x4 *>(nxt + so_b[i]) = rb[i];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int64_t col = n0 + wn + b * 32 + r;
+            if (col >= N) continue;
+            const float bsv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t row = m0 + wm + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row >= M) continue;
+                float v = acc[a][b][e] + bsv;
                 if (EPI == EPI_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                 if (EPI == EPI_ADD_ROW) v += R[row * N + col];
                 if (EPI == EPI_ADD_BCAST) v += R[(row % rmod) * N + col];
@@ -206,10 +320,32 @@ __global__ __launch_bounds__(256) void k_hash_tail(const float *__restrict__ fus
     }
 }
 
+template <int BM, int BN, int EPI>
+static void launch_gemm_lds(const float *A, const float *W, const float *bias, const float *R, int rmod, float *C,
+                            int M, int N, int K, hipStream_t st)
+{
+    constexpr size_t lds = (size_t)2 * (BM + BN) * 36 * sizeof(float);
+    auto kern = k_gemm_lds<BM, BN, EPI>;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid((unsigned)ceil_div(N, BN), (unsigned)ceil_div(M, BM));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, A, W, bias, R, rmod, C, M, N, K);
+}
+
 template <int EPI>
 static void launch_gemm(const float *A, const float *W, const float *bias, const float *R, int rmod,
                         float *C, int M, int N, int K, hipStream_t st)
 {
+    const char *force = getenv("WV_GEMM");   // "stream" pins the LDS-free kernel (tests / tuning)
+    // measured on MI355X at the head's shapes: short-K, wide-N products (mlp.0: K=384, N=1536) run faster on
+    // the LDS-free kernel (118 vs 142 us); everything else on the LDS-tiled one
+    const bool prefer_stream = (K <= 512 && N >= 1024) || (force && !strcmp(force, "stream"));
+    if (K % 32 == 0 && M >= 64 && !prefer_stream) {
+        // largest tile that still gives every CU about two workgroups
+        if (ceil_div(M, 128) * ceil_div(N, 128) >= 512) return launch_gemm_lds<128, 128, EPI>(A, W, bias, R, rmod, C, M, N, K, st);
+        if (ceil_div(M, 128) * ceil_div(N, 64) >= 384) return launch_gemm_lds<128, 64, EPI>(A, W, bias, R, rmod, C, M, N, K, st);
+        return launch_gemm_lds<64, 64, EPI>(A, W, bias, R, rmod, C, M, N, K, st);
+    }
     // big tile when it still yields >= 256 workgroups, else the small one
     const int64_t big = ceil_div(M, 128) * ceil_div(N, 128);
     if (big >= 256) {
