@@ -15,6 +15,7 @@
 // per-thread contiguous ranges are read with fully coalesced loads.  The distance row is not
 // scattered at all: it is regenerated from the bin boundaries (sorted => run-length).
 #include "common.hpp"
+#include <type_traits>
 
 namespace wv {
 
@@ -126,7 +127,9 @@ struct Hist {
     static __host__ __device__ size_t words(int nbins) { return (size_t)nbins * (U16 ? kTopkThreads / 2 : kTopkThreads); }
 };
 
-template <typename Source, bool U16>
+// STAGED: the ranked indices are first placed in an LDS row (scattered 4-byte LDS writes), then copied out
+// with 16-byte coalesced stores -- instead of k scattered 4-byte global stores per query.
+template <typename Source, bool U16, bool STAGED>
 __device__ __forceinline__ void rank_one_query(const Source &src, int64_t n_items, int C, int nbins,
                                                int k, int32_t *__restrict__ idx_out,
                                                uint8_t *__restrict__ dist_out, uint32_t *lds)
@@ -135,6 +138,8 @@ __device__ __forceinline__ void rank_one_query(const Source &src, int64_t n_item
     uint32_t *tot = lds + Hist<U16>::words(nbins);     // kMaxBins
     uint32_t *base = tot + kMaxBins;                   // kMaxBins + 1
     uint32_t *misc = base + kMaxBins + 1;              // [0] = threshold bin T
+    // staging row, 16-byte aligned: starts at the rounded-down word count used by rank_lds_bytes()
+    int32_t *stage = reinterpret_cast<int32_t *>(lds + (Hist<U16>::words(nbins) + kMaxBins + kMaxBins + 1 + 4 + 3) / 4 * 4);
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
 
     {   // zero the table with 16-byte stores
@@ -147,6 +152,8 @@ __device__ __forceinline__ void rank_one_query(const Source &src, int64_t n_item
     // ---- phase 1: private-column histogram.  A column belongs to one thread, so the LDS adds never
     // contend; nothing waits on them.  Distances of the next UNR items are computed while they drain.
     const int64_t first = (int64_t)tid * C;
+    // items of this thread that exist (only the last threads of the last column are short)
+    const int nvalid = (int)min((int64_t)C, max((int64_t)0, n_items - first));
     constexpr int UNR = 16;
     using Raw = typename Source::Raw;
     const int nfull = C / UNR;
@@ -164,12 +171,11 @@ __device__ __forceinline__ void rank_one_query(const Source &src, int64_t n_item
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
-                if (first + r + u < n_items) hist.add(src.dist(cur[u]), tid);
+                if (r + u < nvalid) hist.add(src.dist(cur[u]), tid);
 #pragma unroll
             for (int u = 0; u < UNR; ++u) cur[u] = nxt[u];
         }
-        for (int r = nfull * UNR; r < C; ++r)
-            if (first + r < n_items) hist.add(src.dist(src.fetch(r, tid, first + r)), tid);
+        for (int r = nfull * UNR; r < nvalid; ++r) hist.add(src.dist(src.fetch(r, tid, first + r)), tid);
     }
     __syncthreads();
 
@@ -238,23 +244,37 @@ __device__ __forceinline__ void rank_one_query(const Source &src, int64_t n_item
             for (int u = 0; u < UNR; ++u) {
                 const int d = src.dist(cur[u]);
                 pos[u] = 0xffffffffu;
-                if (first + r + u < n_items && d <= T) pos[u] = hist.fetch_inc(d, tid);
+                if (r + u < nvalid && d <= T) pos[u] = hist.fetch_inc(d, tid);
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
-                if (pos[u] < (uint32_t)k) idx_out[pos[u]] = src.id(first + r + u);
+                if (pos[u] < (uint32_t)k) {
+                    if (STAGED) stage[pos[u]] = src.id(first + r + u);
+                    else idx_out[pos[u]] = src.id(first + r + u);
+                }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) cur[u] = nxt[u];
         }
-        for (int r = nfull * UNR; r < C; ++r) {
+        for (int r = nfull * UNR; r < nvalid; ++r) {
             const int64_t item = first + r;
-            if (item < n_items) {
-                const int d = src.dist(src.fetch(r, tid, item));
-                if (d <= T) {
-                    const uint32_t pos = hist.fetch_inc(d, tid);
-                    if (pos < (uint32_t)k) idx_out[pos] = src.id(item);
+            const int d = src.dist(src.fetch(r, tid, item));
+            if (d <= T) {
+                const uint32_t pos = hist.fetch_inc(d, tid);
+                if (pos < (uint32_t)k) {
+                    if (STAGED) stage[pos] = src.id(item);
+                    else idx_out[pos] = src.id(item);
                 }
             }
+        }
+    }
+    if (STAGED) {   // coalesced copy-out of the ranked row
+        __syncthreads();
+        if ((k & 3) == 0 && (reinterpret_cast<uintptr_t>(idx_out) & 15) == 0) {
+            const int4 *s4 = reinterpret_cast<const int4 *>(stage);
+            int4 *o4 = reinterpret_cast<int4 *>(idx_out);
+            for (int i = tid; i < k / 4; i += kTopkThreads) o4[i] = s4[i];
+        } else {
+            for (int i = tid; i < k; i += kTopkThreads) idx_out[i] = stage[i];
         }
     }
 
@@ -272,10 +292,23 @@ __device__ __forceinline__ void rank_one_query(const Source &src, int64_t n_item
     }
 }
 
-static inline size_t rank_lds_bytes(int nbins, bool u16)
+constexpr int kStageMaxK = 8192;   // ranked rows up to this length are staged in LDS (32 KB)
+static inline size_t rank_fixed_words(int nbins, bool u16)
 {
     const size_t h = (size_t)nbins * (u16 ? kTopkThreads / 2 : kTopkThreads);
-    return (h + kMaxBins + kMaxBins + 1 + 4) * sizeof(uint32_t);
+    return (h + kMaxBins + kMaxBins + 1 + 4 + 3) / 4 * 4;   // 16-byte aligned start of the staging row
+}
+// Measured on MI355X (c1 shape): staging costs a resident workgroup per CU (53 KB vs 34 KB of LDS) and
+// runs 163 us vs 117 us with direct scattered stores -- the kernel is latency-bound, so occupancy wins.
+// Kept selectable (WV_TOPK_STAGE=1) for shapes where the table is small.
+static inline bool rank_staged(int k, int nbins, bool u16)
+{
+    static const bool enabled = getenv("WV_TOPK_STAGE") && getenv("WV_TOPK_STAGE")[0] == '1';
+    return enabled && k <= kStageMaxK && (rank_fixed_words(nbins, u16) + (size_t)k + 4) * 4 <= (size_t)kMaxLdsBytes - 4096;
+}
+static inline size_t rank_lds_bytes(int nbins, bool u16, int k)
+{
+    return (rank_fixed_words(nbins, u16) + (rank_staged(k, nbins, u16) ? (size_t)(k + 3) / 4 * 4 : 0)) * sizeof(uint32_t);
 }
 static inline bool rank_u16(int64_t n_items) { return n_items < 65536; }
 
@@ -296,7 +329,7 @@ __global__ __launch_bounds__(kTopkThreads) void k_transpose_db(const uint64_t *_
     }
 }
 
-template <int WORDS, bool U16>
+template <int WORDS, bool U16, bool STAGED>
 __global__ __launch_bounds__(kTopkThreads) void k_hamming_topk(const uint64_t *__restrict__ q,
                                                                const uint64_t *__restrict__ dbT,
                                                                int32_t *__restrict__ idx,
@@ -311,11 +344,11 @@ __global__ __launch_bounds__(kTopkThreads) void k_hamming_topk(const uint64_t *_
     src.idx_offset = idx_offset;
 #pragma unroll
     for (int w = 0; w < WORDS; ++w) src.qw[w] = q[(int64_t)qi * WORDS + w];
-    rank_one_query<CodeSource<WORDS>, U16>(src, N, C, nbins, k, idx + (int64_t)qi * k,
+    rank_one_query<CodeSource<WORDS>, U16, STAGED>(src, N, C, nbins, k, idx + (int64_t)qi * k,
                                            dist ? dist + (int64_t)qi * k : nullptr, reinterpret_cast<uint32_t *>(lds4));
 }
 
-template <bool U16>
+template <bool U16, bool STAGED>
 __global__ __launch_bounds__(kTopkThreads) void k_topk_merge(const int32_t *__restrict__ idx_in,
                                                              const uint8_t *__restrict__ dist_in,
                                                              int G, int Q, int kin,
@@ -331,11 +364,11 @@ __global__ __launch_bounds__(kTopkThreads) void k_topk_merge(const int32_t *__re
     src.shard_stride = (int64_t)Q * kin;
     src.n = (int64_t)G * kin;
     src.kin = kin;
-    rank_one_query<ListSource, U16>(src, (int64_t)G * kin, C, nbins, k, idx_out + (int64_t)qi * k,
+    rank_one_query<ListSource, U16, STAGED>(src, (int64_t)G * kin, C, nbins, k, idx_out + (int64_t)qi * k,
                                     dist_out ? dist_out + (int64_t)qi * k : nullptr, reinterpret_cast<uint32_t *>(lds4));
 }
 
-template <bool U16>
+template <bool U16, bool STAGED>
 __global__ __launch_bounds__(kTopkThreads) void k_rank_from_dist(const uint8_t *__restrict__ dmat,
                                                                  int64_t ld, int64_t N,
                                                                  int32_t *__restrict__ idx,
@@ -347,7 +380,7 @@ __global__ __launch_bounds__(kTopkThreads) void k_rank_from_dist(const uint8_t *
     RowSource src;
     src.row = dmat + (int64_t)qi * ld;
     src.n = N;
-    rank_one_query<RowSource, U16>(src, N, C, nbins, k, idx + (int64_t)qi * k, dist ? dist + (int64_t)qi * k : nullptr,
+    rank_one_query<RowSource, U16, STAGED>(src, N, C, nbins, k, idx + (int64_t)qi * k, dist ? dist + (int64_t)qi * k : nullptr,
                                    reinterpret_cast<uint32_t *>(lds4));
 }
 
@@ -423,6 +456,14 @@ static int set_lds_attr(const void *fn, size_t bytes, const char *what)
     return WV_OK;
 }
 
+// calls f(std::bool_constant<U16>, std::bool_constant<STAGED>) for the runtime pair
+template <typename F>
+static int dispatch_rank(bool u16, bool staged, F f)
+{
+    if (u16) return staged ? f(std::true_type{}, std::true_type{}) : f(std::true_type{}, std::false_type{});
+    return staged ? f(std::false_type{}, std::true_type{}) : f(std::false_type{}, std::false_type{});
+}
+
 template <int WORDS>
 static int launch_transpose(const uint64_t *db, uint64_t *dbT, int64_t N, hipStream_t st)
 {
@@ -447,17 +488,16 @@ static int launch_topk(const uint64_t *q, const uint64_t *db, const uint64_t *db
         if (rc0) return rc0;
         dbT = (const uint64_t *)ws;
     }
-    const bool u16 = rank_u16(N);
-    const size_t lds = rank_lds_bytes(nbins, u16);
-    int rc = set_lds_attr(u16 ? reinterpret_cast<const void *>(k_hamming_topk<WORDS, true>)
-                              : reinterpret_cast<const void *>(k_hamming_topk<WORDS, false>), lds, "hamming_topk");
+    const bool u16 = rank_u16(N), staged = rank_staged(k, nbins, u16);
+    const size_t lds = rank_lds_bytes(nbins, u16, k);
+    int rc = dispatch_rank(u16, staged, [&](auto U, auto S) {
+        auto kern = k_hamming_topk<WORDS, decltype(U)::value, decltype(S)::value>;
+        int r0 = set_lds_attr(reinterpret_cast<const void *>(kern), lds, "hamming_topk");
+        if (r0) return r0;
+        hipLaunchKernelGGL(kern, dim3(Q), dim3(kTopkThreads), lds, st, q, dbT, idx, dist, N, C, nbins, k, idx_offset);
+        return (int)WV_OK;
+    });
     if (rc) return rc;
-    if (u16)
-        hipLaunchKernelGGL((k_hamming_topk<WORDS, true>), dim3(Q), dim3(kTopkThreads), lds, st, q, dbT, idx, dist,
-                           N, C, nbins, k, idx_offset);
-    else
-        hipLaunchKernelGGL((k_hamming_topk<WORDS, false>), dim3(Q), dim3(kTopkThreads), lds, st, q, dbT, idx, dist,
-                           N, C, nbins, k, idx_offset);
     WV_CHECK_LAUNCH("k_hamming_topk");
     return WV_OK;
 }
@@ -552,17 +592,17 @@ extern "C" int wv_topk_merge(const int32_t *idx_in, const uint8_t *dist_in, int 
     const int64_t items = (int64_t)G * kin;
     const int C = (int)ceil_div(items, kTopkThreads);
     const int nbins = nbits + 2;  // dist = nbits + 1 marks padding entries: they rank after every real one
-    const bool u16 = rank_u16(items);
-    const size_t lds = rank_lds_bytes(nbins, u16);
-    int rc = set_lds_attr(u16 ? reinterpret_cast<const void *>(k_topk_merge<true>)
-                              : reinterpret_cast<const void *>(k_topk_merge<false>), lds, "topk_merge");
+    const bool u16 = rank_u16(items), staged = rank_staged(k, nbins, u16);
+    const size_t lds = rank_lds_bytes(nbins, u16, k);
+    int rc = dispatch_rank(u16, staged, [&](auto U, auto S) {
+        auto kern = k_topk_merge<decltype(U)::value, decltype(S)::value>;
+        int r0 = set_lds_attr(reinterpret_cast<const void *>(kern), lds, "topk_merge");
+        if (r0) return r0;
+        hipLaunchKernelGGL(kern, dim3(Q), dim3(kTopkThreads), lds, (hipStream_t)stream, idx_in, dist_in, G, Q, kin,
+                           idx_out, dist_out, k, C, nbins);
+        return (int)WV_OK;
+    });
     if (rc) return rc;
-    if (u16)
-        hipLaunchKernelGGL(k_topk_merge<true>, dim3(Q), dim3(kTopkThreads), lds, (hipStream_t)stream, idx_in,
-                           dist_in, G, Q, kin, idx_out, dist_out, k, C, nbins);
-    else
-        hipLaunchKernelGGL(k_topk_merge<false>, dim3(Q), dim3(kTopkThreads), lds, (hipStream_t)stream, idx_in,
-                           dist_in, G, Q, kin, idx_out, dist_out, k, C, nbins);
     WV_CHECK_LAUNCH("k_topk_merge");
     return WV_OK;
 }
@@ -577,17 +617,17 @@ extern "C" int wv_rank_from_dist(const uint8_t *dist_matrix, int64_t ld_dist, in
     if (Q == 0) return WV_OK;
     const int C = (int)ceil_div(N, kTopkThreads);
     const int nbins = nbits + 1;
-    const bool u16 = rank_u16(N);
-    const size_t lds = rank_lds_bytes(nbins, u16);
-    int rc = set_lds_attr(u16 ? reinterpret_cast<const void *>(k_rank_from_dist<true>)
-                              : reinterpret_cast<const void *>(k_rank_from_dist<false>), lds, "rank_from_dist");
+    const bool u16 = rank_u16(N), staged = rank_staged(k, nbins, u16);
+    const size_t lds = rank_lds_bytes(nbins, u16, k);
+    int rc = dispatch_rank(u16, staged, [&](auto U, auto S) {
+        auto kern = k_rank_from_dist<decltype(U)::value, decltype(S)::value>;
+        int r0 = set_lds_attr(reinterpret_cast<const void *>(kern), lds, "rank_from_dist");
+        if (r0) return r0;
+        hipLaunchKernelGGL(kern, dim3(Q), dim3(kTopkThreads), lds, (hipStream_t)stream, dist_matrix, ld_dist, N, idx,
+                           dist, k, C, nbins);
+        return (int)WV_OK;
+    });
     if (rc) return rc;
-    if (u16)
-        hipLaunchKernelGGL(k_rank_from_dist<true>, dim3(Q), dim3(kTopkThreads), lds, (hipStream_t)stream,
-                           dist_matrix, ld_dist, N, idx, dist, k, C, nbins);
-    else
-        hipLaunchKernelGGL(k_rank_from_dist<false>, dim3(Q), dim3(kTopkThreads), lds, (hipStream_t)stream,
-                           dist_matrix, ld_dist, N, idx, dist, k, C, nbins);
     WV_CHECK_LAUNCH("k_rank_from_dist");
     return WV_OK;
 }
