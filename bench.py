@@ -237,11 +237,16 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)   # rehearsal: several ranks on one GPU
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("WV_DIST_BACKEND", "nccl")   # "gloo": single-GPU rehearsal of the N>1 path
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     p = Pipeline(args.queries, rank, world, device)
 
@@ -259,8 +264,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ap = out[3]
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    ap_sum = ap.double().sum().reshape(1)
+    cdev = device if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    ap_sum = ap.double().sum().reshape(1).to(cdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(ap_sum)

@@ -25,6 +25,29 @@ def shard_bounds(n_rows, world_size, rank):
     return lo, hi, per
 
 
+def _cpu_staged(group):
+    """gloo moves host memory only: stage through the CPU (rehearsal path; RCCL takes device tensors)."""
+    return dist.get_backend(group) == "gloo"
+
+
+def _all_gather(out, inp, group):
+    if _cpu_staged(group) and inp.is_cuda:
+        o, i = out.cpu(), inp.cpu()
+        dist.all_gather_into_tensor(o, i, group=group)
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
+def _all_to_all(out, inp, group):
+    if _cpu_staged(group) and inp.is_cuda:
+        o, i = out.cpu(), inp.cpu()
+        dist.all_to_all_single(o, i, group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, group=group)
+
+
 def pad_value(nbits):
     """Distance assigned to padding entries of ragged shard lists: sorts after every real entry."""
     return nbits + 1
@@ -43,9 +66,11 @@ def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, works
     kin = min(k, per)                                   # list length every shard sends (padded)
     # 1. every rank needs every query
     q_all = torch.empty((world * Ql, words), dtype=q_local.dtype, device=q_local.device)
-    dist.all_gather_into_tensor(q_all, q_local.contiguous(), group=group)
+    _all_gather(q_all, q_local.contiguous(), group)
     # 2. rank all queries against the local shard
     n_local = hi - lo
+    if not isinstance(db_shard, H.PreparedDB) and db_shard.shape[0] != n_local:
+        raise ValueError(f"rank {rank}: shard has {db_shard.shape[0]} rows, expected rows [{lo}, {hi}) of {n_total}")
     k_local = min(kin, n_local)
     idx_s = torch.full((world * Ql, kin), -1, dtype=torch.int32, device=q_local.device)
     dist_s = torch.full((world * Ql, kin), pad_value(nbits), dtype=torch.uint8, device=q_local.device)
@@ -58,7 +83,7 @@ def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, works
     # 3. exchange: block j of my lists (queries of rank j) goes to rank j
     idx_r = torch.empty_like(idx_s)
     dist_r = torch.empty_like(dist_s)
-    dist.all_to_all_single(idx_r, idx_s.contiguous(), group=group)
-    dist.all_to_all_single(dist_r, dist_s.contiguous(), group=group)
+    _all_to_all(idx_r, idx_s.contiguous(), group)
+    _all_to_all(dist_r, dist_s.contiguous(), group)
     # received layout: [shard g][my Ql queries][kin]  ->  merge
     return H.topk_merge(idx_r.view(world, Ql, kin), dist_r.view(world, Ql, kin), k, nbits)
