@@ -18,6 +18,12 @@
 #include <type_traits>
 #include <vector>
 
+// Folding the u8 -> [0,1] division into the last row-filter taps saves 3 VALU ops per pixel but measured
+// SLOWER on MI355X (1.265 ms vs 1.180 ms, A/B in one session, db2 level 3): off.
+#ifndef WV_SWT_FOLD255
+#define WV_SWT_FOLD255 0
+#endif
+
 namespace wv {
 
 template <int L>
@@ -186,10 +192,22 @@ __device__ __forceinline__ SRaw<InT, LAYOUT> s_fetch4(const InT *__restrict__ im
     return r;
 }
 
-template <typename InT, int LAYOUT>
+// FOLD = true: leave the pixels as integers 0..255 (one v_cvt each); the 1/255 is folded into the taps of the
+// last row-filter level by the caller (the transform is linear).
+template <typename InT, int LAYOUT, bool FOLD = false>
 __device__ __forceinline__ float4 s_convert4(const SRaw<InT, LAYOUT> &r, int c)
 {
-    if constexpr (sizeof(InT) == 1) {
+    if constexpr (sizeof(InT) == 1 && FOLD) {
+        if constexpr (LAYOUT == 1) {
+            const uint32_t s0 = __builtin_amdgcn_alignbyte(r.d[1], r.d[0], (uint32_t)c);
+            const uint32_t s1 = __builtin_amdgcn_alignbyte(r.d[2], r.d[1], (uint32_t)c);
+            const uint32_t s2 = __builtin_amdgcn_alignbyte(0u, r.d[2], (uint32_t)c);
+            return make_float4(s_ubyte<0>(s0), s_ubyte<3>(s0), s_ubyte<2>(s1), s_ubyte<1>(s2));
+        } else {
+            const uint32_t d = r.d[0];
+            return make_float4(s_ubyte<0>(d), s_ubyte<1>(d), s_ubyte<2>(d), s_ubyte<3>(d));
+        }
+    } else if constexpr (sizeof(InT) == 1) {
         if constexpr (LAYOUT == 1) {  // channel c at bytes c, 3+c, 6+c, 9+c of the 12
             const uint32_t s0 = __builtin_amdgcn_alignbyte(r.d[1], r.d[0], (uint32_t)c);
             const uint32_t s1 = __builtin_amdgcn_alignbyte(r.d[2], r.d[1], (uint32_t)c);
@@ -242,6 +260,13 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
     const bool is_h = threadIdx.x >= NH;                  // wave-uniform role
     const int t = is_h ? threadIdx.x - NH : threadIdx.x;
 
+    constexpr bool FOLD = sizeof(InT) == 1 && WV_SWT_FOLD255;
+    float hlo[L], hhi[L];   // taps of the last row-filter level (scaled by 1/255 when the division is folded)
+#pragma unroll
+    for (int m = 0; m < L; ++m) {
+        hlo[m] = FOLD ? taps.lo[m] * 0.003921568859368563f : taps.lo[m];
+        hhi[m] = FOLD ? taps.hi[m] * 0.003921568859368563f : taps.hi[m];
+    }
     if (is_h) {
         // ------------------------------------------------------------------ producer: pass H
         const int rr = t / g.nrun, j = t - rr * g.nrun;
@@ -267,7 +292,7 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
                     float v[NG * 4];
 #pragma unroll
                     for (int q = 0; q < NG; ++q) {
-                        const float4 p4 = s_convert4<InT, LAYOUT>(raw[q], c);
+                        const float4 p4 = s_convert4<InT, LAYOUT, FOLD>(raw[q], c);
                         v[4 * q + 0] = p4.x; v[4 * q + 1] = p4.y; v[4 * q + 2] = p4.z; v[4 * q + 3] = p4.w;
                     }
                     WV_STAMP(st1);
@@ -288,10 +313,10 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
 #pragma unroll
                     for (int q4 = 0; q4 < R / 4; ++q4) {
                         float4 lo4, hi4;
-                        lo4.x = CH::last(w, taps.lo, 4 * q4 + 0); hi4.x = CH::last(w, taps.hi, 4 * q4 + 0);
-                        lo4.y = CH::last(w, taps.lo, 4 * q4 + 1); hi4.y = CH::last(w, taps.hi, 4 * q4 + 1);
-                        lo4.z = CH::last(w, taps.lo, 4 * q4 + 2); hi4.z = CH::last(w, taps.hi, 4 * q4 + 2);
-                        lo4.w = CH::last(w, taps.lo, 4 * q4 + 3); hi4.w = CH::last(w, taps.hi, 4 * q4 + 3);
+                        lo4.x = CH::last(w, hlo, 4 * q4 + 0); hi4.x = CH::last(w, hhi, 4 * q4 + 0);
+                        lo4.y = CH::last(w, hlo, 4 * q4 + 1); hi4.y = CH::last(w, hhi, 4 * q4 + 1);
+                        lo4.z = CH::last(w, hlo, 4 * q4 + 2); hi4.z = CH::last(w, hhi, 4 * q4 + 2);
+                        lo4.w = CH::last(w, hlo, 4 * q4 + 3); hi4.w = CH::last(w, hhi, 4 * q4 + 3);
                         *reinterpret_cast<float4 *>(plo + q4 * qstride) = lo4;
                         *reinterpret_cast<float4 *>(phi + q4 * qstride) = hi4;
                     }
