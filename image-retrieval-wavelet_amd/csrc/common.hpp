@@ -56,21 +56,24 @@ __device__ __forceinline__ int mbcnt(uint64_t mask)
                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
 
+// Wave64 inclusive scan on the DPP network (no LDS round trips): row_shr 1/2/4/8 inside each row of 16
+// lanes, then row_bcast15 / row_bcast31 carry the row totals forward (the sequence LLVM's atomic
+// optimizer emits for gfx9).  ~6 VALU instructions instead of 6 ds_bpermute round trips.
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t n = __shfl_up(v, d, 64);
-        if (lane_id() >= d) v += n;
-    }
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
     return v;
 }
 
+// sum over the wave, returned in every lane
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(v), 63);
 }
 
 __device__ __forceinline__ double wave_sum_f64(double v)

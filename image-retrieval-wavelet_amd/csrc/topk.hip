@@ -20,6 +20,7 @@
 namespace wv {
 
 constexpr int kTopkThreads = 256;
+__device__ int g_topk_dbg = 0;   // WV_TOPK_DBG (timing experiments only): 1 = no list stores, 2 = skip phase 2, 4 = skip phase 1
 constexpr int kMaxBins = 130;  // nbits <= 128 (+1 bin for the padding value of ragged shard lists)
 
 // ------------------------------------------------------------------------ item sources
@@ -157,7 +158,36 @@ __device__ __forceinline__ void rank_one_query(const Source &src, int64_t n_item
     constexpr int UNR = 16;
     using Raw = typename Source::Raw;
     const int nfull = C / UNR;
-    {
+    const int dbg = g_topk_dbg;
+    // Columns of at most kCacheItems items keep their distances (one byte each) in registers between the
+    // two phases, so phase 2 neither reloads the codes nor recomputes the popcounts.
+    constexpr int kCacheItems = 128, kCacheBatches = kCacheItems / UNR;
+    const bool cached = C <= kCacheItems;            // uniform
+    uint32_t dcache[kCacheItems / 4];
+    if (cached) {
+        if (!(dbg & 4)) {
+#pragma unroll
+            for (int bi = 0; bi < kCacheBatches; ++bi) {
+                if (bi * UNR < C) {                   // uniform
+                    Raw cur[UNR];
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) cur[u] = src.fetch(min(bi * UNR + u, C - 1), tid, first + bi * UNR + u);
+#pragma unroll
+                    for (int u4 = 0; u4 < UNR / 4; ++u4) {
+                        uint32_t word = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int u = 4 * u4 + j;
+                            const int d = src.dist(cur[u]);
+                            word |= (uint32_t)d << (8 * j);
+                            if (bi * UNR + u < nvalid) hist.add(d, tid);
+                        }
+                        dcache[bi * (UNR / 4) + u4] = word;
+                    }
+                }
+            }
+        }
+    } else if (!(dbg & 4)) {
         Raw cur[UNR], nxt[UNR];
         if (nfull > 0) {
 #pragma unroll
@@ -227,7 +257,28 @@ __device__ __forceinline__ void rank_one_query(const Source &src, int64_t n_item
     __syncthreads();
 
     // ---- phase 2: stable placement of the items in bins <= T (returning LDS adds, UNR in flight)
-    {
+    if (cached) {
+        if (!(dbg & 2)) {
+#pragma unroll
+            for (int bi = 0; bi < kCacheBatches; ++bi) {
+                if (bi * UNR < C) {
+                    uint32_t pos[UNR];
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        const int d = (dcache[bi * (UNR / 4) + u / 4] >> (8 * (u & 3))) & 0xff;
+                        pos[u] = 0xffffffffu;
+                        if (bi * UNR + u < nvalid && d <= T) pos[u] = hist.fetch_inc(d, tid);
+                    }
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u)
+                        if (pos[u] < (uint32_t)k && !(dbg & 1)) {
+                            if (STAGED) stage[pos[u]] = src.id(first + bi * UNR + u);
+                            else idx_out[pos[u]] = src.id(first + bi * UNR + u);
+                        }
+                }
+            }
+        }
+    } else if (!(dbg & 2)) {
         Raw cur[UNR], nxt[UNR];
         if (nfull > 0) {
 #pragma unroll
@@ -248,7 +299,7 @@ __device__ __forceinline__ void rank_one_query(const Source &src, int64_t n_item
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
-                if (pos[u] < (uint32_t)k) {
+                if (pos[u] < (uint32_t)k && !(dbg & 1)) {
                     if (STAGED) stage[pos[u]] = src.id(first + r + u);
                     else idx_out[pos[u]] = src.id(first + r + u);
                 }
@@ -260,7 +311,7 @@ __device__ __forceinline__ void rank_one_query(const Source &src, int64_t n_item
             const int d = src.dist(src.fetch(r, tid, item));
             if (d <= T) {
                 const uint32_t pos = hist.fetch_inc(d, tid);
-                if (pos < (uint32_t)k) {
+                if (pos < (uint32_t)k && !(dbg & 1)) {
                     if (STAGED) stage[pos] = src.id(item);
                     else idx_out[pos] = src.id(item);
                 }
@@ -278,16 +329,36 @@ __device__ __forceinline__ void rank_one_query(const Source &src, int64_t n_item
         }
     }
 
-    // ---- distance row from the bin boundaries: dist[p] = b  with  base[b] <= p < base[b+1]
+    // ---- distance row from the bin boundaries: dist[p] = b  with  base[b] <= p < base[b+1].
+    // Each thread owns a run of positions: one binary search, then it walks the boundaries; 4 bytes per store.
     if (dist_out) {
-        for (int p = tid; p < k; p += kTopkThreads) {
-            int lo = 0, hi = nbins;  // invariant: base[lo] <= p < base[hi]
+        const int chunk = ((k + kTopkThreads - 1) / kTopkThreads + 3) & ~3;
+        const int p0 = tid * chunk;
+        if (p0 < k) {
+            int lo = 0, hi = nbins;  // invariant: base[lo] <= p0 < base[hi]
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
-                if (base[mid] <= (uint32_t)p) lo = mid;
+                if (base[mid] <= (uint32_t)p0) lo = mid;
                 else hi = mid;
             }
-            dist_out[p] = (uint8_t)lo;
+            int bin = lo;
+            uint32_t next = base[bin + 1];
+            const bool aligned = (reinterpret_cast<uintptr_t>(dist_out) & 3) == 0;
+            for (int i = 0; i < chunk; i += 4) {
+                uint32_t word = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t p = (uint32_t)(p0 + i + j);
+                    while (p >= next && bin + 1 < nbins) { ++bin; next = base[bin + 1]; }
+                    word |= (uint32_t)bin << (8 * j);
+                }
+                if (aligned && p0 + i + 4 <= k) {
+                    *reinterpret_cast<uint32_t *>(dist_out + p0 + i) = word;
+                } else {
+                    for (int j = 0; j < 4; ++j)
+                        if (p0 + i + j < k) dist_out[p0 + i + j] = (uint8_t)(word >> (8 * j));
+                }
+            }
         }
     }
 }
@@ -490,6 +561,10 @@ static int launch_topk(const uint64_t *q, const uint64_t *db, const uint64_t *db
     }
     const bool u16 = rank_u16(N), staged = rank_staged(k, nbins, u16);
     const size_t lds = rank_lds_bytes(nbins, u16, k);
+    if (const char *e = getenv("WV_TOPK_DBG")) {
+        const int v = atoi(e);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_topk_dbg), &v, sizeof(int));
+    }
     int rc = dispatch_rank(u16, staged, [&](auto U, auto S) {
         auto kern = k_hamming_topk<WORDS, decltype(U)::value, decltype(S)::value>;
         int r0 = set_lds_attr(reinterpret_cast<const void *>(kern), lds, "hamming_topk");
