@@ -176,7 +176,7 @@ def load_traffic(kernel_name):
             t = json.load(f)
         for key, val in t.items():
             if key in kernel_name:
-                return val
+                return val["hbm_bytes_per_launch"] if isinstance(val, dict) else val
     except (OSError, ValueError):
         pass
     return None
