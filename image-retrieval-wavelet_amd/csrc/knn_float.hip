@@ -136,11 +136,13 @@ __device__ __forceinline__ float key_to_float(uint32_t u, bool descending)
 // One stable counting-sort pass over digit (key >> shift) & 63 of every row.
 // first: source is the score matrix (key derived, idx = column); last: only ranks < k are written,
 // to idx_out / val_out.
+// Intermediate (key, idx) arrays are kept in the column image pos -> [pos % C][pos / C] ("transposed"), so
+// that thread t's contiguous range [t*C, (t+1)*C) of the NEXT pass is read with coalesced loads.
 __global__ __launch_bounds__(kRadixThreads) void k_radix_pass(const float *__restrict__ S,
                                                               const uint2 *__restrict__ src,
                                                               uint2 *__restrict__ dst, int64_t N, int C,
-                                                              int shift, int first, int last, int k,
-                                                              int descending, int32_t *__restrict__ idx_out,
+                                                              uint32_t c_magic, int shift, int first, int last,
+                                                              int k, int descending, int32_t *__restrict__ idx_out,
                                                               float *__restrict__ val_out)
 {
     __shared__ uint32_t hist[kRadixBins * kRadixThreads];  // 64 KB
@@ -148,20 +150,41 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_pass(const float *__res
     __shared__ uint32_t base[kRadixBins];
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     const int64_t row = blockIdx.x;
+    const int64_t pitch = (int64_t)C * kRadixThreads;   // padded row length of the transposed images
     const float *Srow = S + row * N;
-    const uint2 *srow = src + row * N;
-    uint2 *drow = dst + row * N;
+    const uint2 *srow = src + row * pitch;
+    uint2 *drow = dst + row * pitch;
 
-    for (int i = tid; i < kRadixBins * kRadixThreads; i += kRadixThreads) hist[i] = 0;
+    {
+        uint4 *h4 = reinterpret_cast<uint4 *>(hist);
+        for (int i = tid; i < kRadixBins * kRadixThreads / 4; i += kRadixThreads) h4[i] = make_uint4(0, 0, 0, 0);
+    }
     __syncthreads();
     const int64_t first_item = (int64_t)tid * C;
-    for (int r = 0; r < C; ++r) {
-        const int64_t item = first_item + r;
-        if (item < N) {
-            const uint32_t key = first ? float_to_key(Srow[item], descending) : srow[item].x;
-            hist[((key >> shift) & (kRadixBins - 1)) * kRadixThreads + tid] += 1;
+    const int nvalid = (int)min((int64_t)C, max((int64_t)0, N - first_item));
+    constexpr int UNR = 8;
+    auto fetch = [&](int r) -> uint2 {
+        if (first) {
+            const int64_t item = first_item + r;
+            return make_uint2(float_to_key(Srow[min(item, N - 1)], descending), (uint32_t)item);
         }
+        return srow[(int64_t)r * kRadixThreads + tid];
+    };
+    // counting: a column belongs to one thread -> the LDS adds never contend and nothing waits on them
+    int r = 0;
+    for (; r + UNR <= C; r += UNR) {
+        uint2 kv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) kv[u] = fetch(r + u);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (r + u < nvalid)
+                __hip_atomic_fetch_add(&hist[((kv[u].x >> shift) & (kRadixBins - 1)) * kRadixThreads + tid], 1u,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    for (; r < nvalid; ++r)
+        __hip_atomic_fetch_add(&hist[((fetch(r).x >> shift) & (kRadixBins - 1)) * kRadixThreads + tid], 1u,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
     for (int b = wv; b < kRadixBins; b += kRadixThreads / 64) {
         const uint4 v = *reinterpret_cast<const uint4 *>(hist + b * kRadixThreads + 4 * lane);
@@ -183,29 +206,44 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_pass(const float *__res
         *reinterpret_cast<uint4 *>(hist + b * kRadixThreads + 4 * lane) = o;
     }
     __syncthreads();
-    for (int r = 0; r < C; ++r) {
-        const int64_t item = first_item + r;
-        if (item < N) {
-            uint2 kv;
-            if (first) kv = make_uint2(float_to_key(Srow[item], descending), (uint32_t)item);
-            else kv = srow[item];
-            const uint32_t pos = hist[((kv.x >> shift) & (kRadixBins - 1)) * kRadixThreads + tid]++;
-            if (last) {
-                if (pos < (uint32_t)k) {
-                    idx_out[row * k + pos] = (int32_t)kv.y;
-                    val_out[row * k + pos] = key_to_float(kv.x, descending);
-                }
-            } else {
-                drow[pos] = kv;
+    auto place = [&](const uint2 &kv, uint32_t pos) {
+        if (last) {
+            if (pos < (uint32_t)k) {
+                idx_out[row * k + pos] = (int32_t)kv.y;
+                val_out[row * k + pos] = key_to_float(kv.x, descending);
             }
+        } else {
+            const uint32_t tq = C == 1 ? pos : __umulhi(pos, c_magic);   // pos / C
+            drow[(int64_t)(pos - tq * C) * kRadixThreads + tq] = kv;
         }
+    };
+    for (r = 0; r + UNR <= C; r += UNR) {
+        uint2 kv[UNR];
+        uint32_t pos[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) kv[u] = fetch(r + u);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            pos[u] = 0xffffffffu;
+            if (r + u < nvalid)
+                pos[u] = __hip_atomic_fetch_add(&hist[((kv[u].x >> shift) & (kRadixBins - 1)) * kRadixThreads + tid], 1u,
+                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (pos[u] != 0xffffffffu) place(kv[u], pos[u]);
+    }
+    for (; r < nvalid; ++r) {
+        const uint2 kv = fetch(r);
+        place(kv, __hip_atomic_fetch_add(&hist[((kv.x >> shift) & (kRadixBins - 1)) * kRadixThreads + tid], 1u,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     }
 }
 
 static int64_t knn_chunk_rows(int Q, int64_t N)
 {
     // bound the scratch to about 2 GiB: per row N * (4 + 8 + 8) bytes
-    const int64_t per_row = N * 20;
+    const int64_t per_row = N * 4 + ceil_div(N, kRadixThreads) * kRadixThreads * 16;
     int64_t rows = (2ll << 30) / std::max<int64_t>(per_row, 1);
     rows = std::max<int64_t>(rows, 1);
     return std::min<int64_t>(rows, Q);
@@ -220,7 +258,8 @@ extern "C" size_t wv_knn_float_workspace_bytes(int Q, int64_t N, int D, int k)
     (void)D; (void)k;
     if (Q <= 0 || N <= 0) return 0;
     const int64_t rows = knn_chunk_rows(Q, N);
-    return (size_t)(rows * N * 20 + (align_up(Q, 64) + align_up(N, 64)) * 4 + 256);
+    const int64_t pitch = ceil_div(N, kRadixThreads) * kRadixThreads;
+    return (size_t)(rows * (N * 4 + pitch * 16) + (align_up(Q, 64) + align_up(N, 64)) * 4 + 1024);
 }
 
 extern "C" int wv_knn_float(const float *q, const float *db, int Q, int64_t N, int D, int metric, int k,
@@ -232,7 +271,7 @@ extern "C" int wv_knn_float(const float *q, const float *db, int Q, int64_t N, i
     WV_REQUIRE(metric == WV_METRIC_IP || metric == WV_METRIC_L2, "knn_float: metric %d", metric);
     WV_REQUIRE(k >= 1 && k <= N, "knn_float: k=%d must be in [1, N=%lld] (torch.topk raises too)", k,
                (long long)N);
-    WV_REQUIRE(N <= 0x7fffffffLL, "knn_float: N exceeds int32 indices");
+    WV_REQUIRE(N <= (1ll << 26), "knn_float: N=%lld above the supported 2^26 rows", (long long)N);
     WV_REQUIRE((D % 4) == 0, "knn_float: embedding dimension %d must be a multiple of 4", D);
     const size_t need = wv_knn_float_workspace_bytes(Q, N, D, k);
     if (!workspace || workspace_bytes < need)
@@ -241,9 +280,10 @@ extern "C" int wv_knn_float(const float *q, const float *db, int Q, int64_t N, i
     hipStream_t st = (hipStream_t)stream;
     const int64_t rows = knn_chunk_rows(Q, N);
     char *w = (char *)workspace;
-    float *S = (float *)w;                 w += rows * N * 4;
-    uint2 *bufA = (uint2 *)w;              w += rows * N * 8;
-    uint2 *bufB = (uint2 *)w;              w += rows * N * 8;
+    const int64_t pitch = ceil_div(N, kRadixThreads) * kRadixThreads;
+    float *S = (float *)w;                 w += align_up(rows * N * 4, 256);
+    uint2 *bufA = (uint2 *)w;              w += rows * pitch * 8;
+    uint2 *bufB = (uint2 *)w;              w += rows * pitch * 8;
     float *qn = (float *)w;                w += align_up(Q, 64) * 4;
     float *dbn = (float *)w;
     if (metric == WV_METRIC_L2) {
@@ -251,6 +291,7 @@ extern "C" int wv_knn_float(const float *q, const float *db, int Q, int64_t N, i
         hipLaunchKernelGGL(k_row_sqnorm, dim3((unsigned)ceil_div(N, 4)), dim3(256), 0, st, db, N, D, dbn);
     }
     const int C = (int)ceil_div(N, kRadixThreads);
+    const uint32_t c_magic = C <= 1 ? 0u : (uint32_t)(((1ull << 32) + C - 1) / C);   // exact for pos < 2^32 / C
     const int descending = metric == WV_METRIC_IP;
     for (int64_t q0 = 0; q0 < Q; q0 += rows) {
         const int qc = (int)std::min<int64_t>(rows, Q - q0);
@@ -262,7 +303,7 @@ extern "C" int wv_knn_float(const float *q, const float *db, int Q, int64_t N, i
         for (int p = 0; p < npass; ++p) {
             src = (p & 1) ? bufA : bufB;
             dst = (p & 1) ? bufB : bufA;
-            hipLaunchKernelGGL(k_radix_pass, dim3(qc), dim3(kRadixThreads), 0, st, S, src, dst, N, C,
+            hipLaunchKernelGGL(k_radix_pass, dim3(qc), dim3(kRadixThreads), 0, st, S, src, dst, N, C, c_magic,
                                p * kRadixBits, p == 0, p == npass - 1, k, descending, idx + q0 * k,
                                val + q0 * k);
         }

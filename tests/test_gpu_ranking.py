@@ -237,3 +237,34 @@ def test_get_accuracy_driver_metrics():
     assert abs(acc["bit_balance"] - ranking.calculate_bit_balance(r)) < 1e-6
     idx, acc2 = calc.get_accuracy(q, ql, r, rl, False, return_indices=True)
     assert torch.equal(idx.cpu(), si) and acc2 == acc
+
+
+def test_coco_shape_128bit_u32_path_k5000_and_all():
+    """BASELINE c3 shape: N = 117,218 codes of 128 bit (counters no longer fit 16 bits, columns longer than the
+    register cache), k = 5000 and k = N (mAP@ALL); oracle on 4 queries."""
+    Q, N, nbits = 4, 117218, 128
+    ql, rl = synth.multi_hot_labels(Q, 80, 0.036, 1), synth.multi_hot_labels(N, 80, 0.036, 2)
+    q, r = synth.structured_codes(ql, nbits, 3, 4), synth.structured_codes(rl, nbits, 3, 5)
+    qp, rp = H.pack_codes(q.cuda()), H.pack_codes(r.cuda())
+    prep = H.PreparedDB(rp, nbits)
+    for k in (5000, N):
+        idx, dk = H.hamming_topk(qp, prep, nbits, k)
+        ref_idx, ref_dk = ranking.hamming_topk_stable(q, r, k)
+        assert torch.equal(idx.cpu().long(), ref_idx) and torch.equal(dk.cpu().long(), ref_dk)
+        calc = CustomCalculator(k=k, distance_metric="hamming", with_faiss=False)
+        m = calc.calculate_maphashing(q, ql, r, rl, k)
+        assert abs(m - ranking.calculate_maphashing(q, ql, r, rl, k, stable=True)) < AP_TOL
+    d = H.hamming_dist(qp, prep)
+    assert torch.equal(d.cpu().long(), ranking.hamming_matrix_u8(q, r))
+
+
+def test_voc_shape_16bit_full_gallery():
+    """BASELINE c0 shape: N = 5717, 16 bit, k = N, Lc = 20."""
+    Q, N, nbits = 96, 5717, 16
+    ql, rl = synth.multi_hot_labels(Q, 20, 0.07, 1), synth.multi_hot_labels(N, 20, 0.07, 2)
+    q, r = synth.structured_codes(ql, nbits, 3, 4), synth.structured_codes(rl, nbits, 3, 5)
+    calc = CustomCalculator(k=N, distance_metric="hamming", with_faiss=False)
+    m, ap = calc.calculate_maphashing(q, ql, r, rl, N, return_per_query=True)
+    m_ref, ap_ref = ranking.calculate_maphashing(q, ql, r, rl, N, stable=True, return_per_query=True)
+    np.testing.assert_allclose(ap.cpu().numpy(), ap_ref, atol=AP_TOL)
+    assert abs(m - m_ref) < AP_TOL

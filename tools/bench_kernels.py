@@ -60,6 +60,13 @@ def main():
         rl = H.pack_labels(synth.multi_hot_labels(N, 38, 0.1, 2).cuda())
         ms = timeit(lambda: H.map_at_k(idx, ql, rl), a.reps)
         print(f"map_at_k: {ms * 1e3:.1f} us", flush=True)
+    if "knn" in a.what:
+        from wvhash.engine import get_knn
+        g = torch.Generator().manual_seed(0)
+        for metric, D, k in (("l2", 384, 5000), ("cosine", 384, 5000), ("l2", 64, 100)):
+            qe, re_ = torch.randn(Q, D, generator=g).cuda(), torch.randn(N, D, generator=g).cuda()
+            ms = timeit(lambda: get_knn(re_, qe, k, False, distance_metric=metric), max(2, a.reps // 5))
+            print(f"knn_float {metric} D={D} k={k}: {ms:.3f} ms  {Q / ms * 1e3:.0f} q/s", flush=True)
     if "head" in a.what:
         from wvhash.models import get_fusion_head
         head = get_fusion_head({"type": "cross_attention_advanced", "output_dim": 384, "num_queries": 4}, [384] * 4)
