@@ -51,17 +51,21 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--queries", type=int, default=Q_PER_GPU, help="query images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("WV_BENCH_STREAMS", "1")), choices=(1, 2),
+                    help="2: the SWT of a batch runs on its own HIP stream beside head/hash/ranking (stage pipelining)")
     ap.add_argument("--kernel-reps", type=int, default=10, help="launches per stage for the roofline timing")
     return ap.parse_args()
 
 
 class Pipeline:
-    def __init__(self, Q, rank, world, device):
+    def __init__(self, Q, rank, world, device, streams=1):
         from wvhash import synth
         from wvhash.engine import hamming as Hm
         from wvhash.models import get_fusion_head
         from wvhash.parallel import shard_bounds
         self.Q, self.rank, self.world, self.dev = Q, rank, world, device
+        self.swt_stream = torch.cuda.Stream(device=device) if streams == 2 else None
+        self.bands = torch.empty((Q, 3, 4, H, W), dtype=torch.float32, device=device)
         g = torch.Generator(device="cpu").manual_seed(1234 + rank)
         self.images = torch.randint(0, 256, (Q, H, W, 3), generator=g, dtype=torch.uint8).to(device)
         self.feats = [f.to(device) for f in synth.band_features(Q, EMBED, seed=100 + rank)]
@@ -94,7 +98,7 @@ class Pipeline:
     # -- the stages (each one C-ABI call) ---------------------------------------------------
     def stage_swt(self):
         from wvhash.transforms import swt2d
-        return swt2d(self.images, WAVELET, LEVEL, channels_last=True)
+        return swt2d(self.images, WAVELET, LEVEL, channels_last=True, out=self.bands)
 
     def stage_head(self):
         return self.head(self.feats)
@@ -112,11 +116,21 @@ class Pipeline:
 
     @torch.no_grad()
     def step(self):
-        bands = self.stage_swt()
+        if self.swt_stream is not None:
+            # stage pipelining: in the full system the backbone sits between the SWT and the head, so in steady
+            # state the transform of one batch runs beside head/hash/ranking of the previous one
+            main = torch.cuda.current_stream()
+            self.swt_stream.wait_stream(main)
+            with torch.cuda.stream(self.swt_stream):
+                bands = self.stage_swt()
+        else:
+            bands = self.stage_swt()
         fused = self.stage_head()
         packed = self.stage_tail(fused)
         idx, _ = self.stage_rank(packed)
         ap, _ = self.stage_map(idx)
+        if self.swt_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.swt_stream)
         return bands, packed, idx, ap
 
 
@@ -249,7 +263,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    p = Pipeline(args.queries, rank, world, device)
+    p = Pipeline(args.queries, rank, world, device, streams=args.streams)
 
     def barrier():
         if world > 1:

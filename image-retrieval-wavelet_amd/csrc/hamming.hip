@@ -254,13 +254,12 @@ __global__ __launch_bounds__(256) void k_hamming_dist_prep(const uint64_t *__res
     }
 }
 
-template <int WORDS>
-static int launch_dist_prep(const uint64_t *q, const void *dbP, uint8_t *dist, int64_t ld, int Q, int64_t N,
-                            hipStream_t st)
+template <int WORDS, int QCH>
+static int launch_dist_prep_q(const uint64_t *q, const void *dbP, uint8_t *dist, int64_t ld, int Q, int64_t N,
+                              hipStream_t st)
 {
     using Cfg = DistCfg<WORDS>;
     const int64_t tiles = ceil_div(N, Cfg::TILE);
-    constexpr int QCH = 8;
     const int64_t qblocks = ceil_div(Q, QCH);
     if (tiles > 0x7fffffff || qblocks > 65535) WV_FAIL(WV_ENOTSUP, "hamming_dist: grid too large");
     const bool aligned = (ld % 16 == 0) && ((reinterpret_cast<uintptr_t>(dist) & 15) == 0);
@@ -271,6 +270,26 @@ static int launch_dist_prep(const uint64_t *q, const void *dbP, uint8_t *dist, i
         hipLaunchKernelGGL((k_hamming_dist_prep<WORDS, false, QCH>), grid, dim3(256), 0, st, q, (const uint4 *)dbP, dist, ld, Q, N);
     WV_CHECK_LAUNCH("k_hamming_dist_prep");
     return WV_OK;
+}
+
+template <int WORDS>
+static int launch_dist_prep(const uint64_t *q, const void *dbP, uint8_t *dist, int64_t ld, int Q, int64_t N,
+                            hipStream_t st)
+{
+    using Cfg = DistCfg<WORDS>;
+    // queries per workgroup: enough workgroups for ~2 generations per CU slot, so that the loads of one
+    // generation overlap the output stream of the previous one
+    int qch = 8;
+    const int64_t tiles = ceil_div(N, Cfg::TILE);
+    while (qch > 2 && tiles * ceil_div(Q, qch) < 4096) qch >>= 1;
+    while (qch < 16 && ceil_div(Q, qch) > 65535) qch <<= 1;
+    if (const char *e = getenv("WV_DIST_QCH")) qch = atoi(e);
+    switch (qch) {
+    case 2: return launch_dist_prep_q<WORDS, 2>(q, dbP, dist, ld, Q, N, st);
+    case 4: return launch_dist_prep_q<WORDS, 4>(q, dbP, dist, ld, Q, N, st);
+    case 16: return launch_dist_prep_q<WORDS, 16>(q, dbP, dist, ld, Q, N, st);
+    default: return launch_dist_prep_q<WORDS, 8>(q, dbP, dist, ld, Q, N, st);
+    }
 }
 
 template <int WORDS>

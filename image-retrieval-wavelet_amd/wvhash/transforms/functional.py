@@ -25,12 +25,13 @@ def _in_dtype(x):
     raise TypeError(f"images must be uint8 (0..255) or float32 (already scaled), got {x.dtype}")
 
 
-def swt2d(x, wavelet="haar", level=1, channels_last=False, out_dtype=torch.float32):
+def swt2d(x, wavelet="haar", level=1, channels_last=False, out_dtype=torch.float32, out=None):
     """Batch of images on the GPU -> [B, C, 4, H, W] level-`level` sub-bands (cA, cH, cV, cD).
 
     Same numbers as stacking ``SWTTransform(level, wavelet)(img)`` of the reference
     (custom_transforms.py:145-166) over the batch: uint8 input is divided by 255 in fp32,
     float32 input is used as is.  ``channels_last`` = the batch is [B, H, W, C] (PIL layout).
+    ``out`` = preallocated result buffer (reused across steps, e.g. when the transform runs on its own stream).
     """
     lib = _lib.require_gpu()
     if not x.is_cuda:
@@ -44,7 +45,10 @@ def swt2d(x, wavelet="haar", level=1, channels_last=False, out_dtype=torch.float
         odt = _lib.WV_DT_BF16
     else:
         raise TypeError("out_dtype must be float32 or bfloat16")
-    out = torch.empty((B, C, 4, H, W), dtype=out_dtype, device=x.device)
+    if out is None:
+        out = torch.empty((B, C, 4, H, W), dtype=out_dtype, device=x.device)
+    elif tuple(out.shape) != (B, C, 4, H, W) or out.dtype != out_dtype or not out.is_contiguous() or out.device != x.device:
+        raise ValueError("swt2d: `out` must be a contiguous [B, C, 4, H, W] tensor of out_dtype on the input's device")
     if B == 0:
         return out
     if H % (1 << level) or W % (1 << level):

@@ -49,6 +49,15 @@ def main():
     if "dist" in a.what:
         ms = timeit(lambda: H.hamming_dist(qp, rp), a.reps)
         print(f"hamming_dist: {ms * 1e3:.1f} us  {(Q * N + (Q + N) * 8) / ms / 1e6:.0f} GB/s", flush=True)
+        prep = H.PreparedDB(rp, 64)
+        out = torch.empty((Q, (N + 63) // 64 * 64), dtype=torch.uint8, device="cuda")
+        import ctypes
+        from wvhash import _lib
+        lib = _lib.load()
+        def raw():   # no allocation / Python wrapper in the loop: kernel launch cost only
+            lib.wv_hamming_dist_prepared(_lib.ptr(qp), _lib.ptr(prep.blob), _lib.ptr(out), out.shape[1], Q, N, 1, _lib.stream_ptr())
+        ms = timeit(raw, a.reps)
+        print(f"hamming_dist_prepared (raw C call): {ms * 1e3:.1f} us  {(Q * N + (Q + N) * 8) / ms / 1e6:.0f} GB/s", flush=True)
     if "topk" in a.what:
         ws = H.TopkWorkspace()
         for k in (5000,):
