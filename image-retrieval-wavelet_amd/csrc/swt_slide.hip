@@ -237,6 +237,19 @@ __device__ __forceinline__ float4 s_convert4(const SRaw<InT, LAYOUT> &r, int c)
 // STAMP = true is a diagnostic build (WV_SWT_STAMPS=1): per-wave s_memtime totals of the three segments of
 // each role go to g.stamps (never read by the kernel, never part of an output).
 #define WV_STAMP(var) do { if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } } while (0)
+// Store through "SGPR base + 32-bit lane offset" addressing (global_store ... saddr): the row pointer is
+// wave-uniform, so no per-store 64-bit vector address arithmetic is needed.  hipcc builds the address in
+// VGPRs for this pattern, hence the explicit instruction.  Only V waves store and they issue no vector
+// loads in their loop, so the compiler's vmcnt bookkeeping is unaffected.
+__device__ __forceinline__ void store_row(float *row_uniform, uint32_t byte_off, float v)
+{
+    asm volatile("global_store_dword %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(row_uniform) : "memory");
+}
+__device__ __forceinline__ void store_row(__hip_bfloat16 *row_uniform, uint32_t byte_off, __hip_bfloat16 v)
+{
+    *reinterpret_cast<__hip_bfloat16 *>(reinterpret_cast<char *>(row_uniform) + byte_off) = v;
+}
+
 template <int L, int NLEV, int R, int TH, int NH, int MINW, typename InT, int LAYOUT, bool BF16, bool STAMP = false>
 __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restrict__ in, void *__restrict__ out,
                                                             SlideGeom g, STaps<L> taps)
@@ -354,13 +367,15 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
                         if (y0 + TH <= 0) {               // nothing to emit yet: only advance the state
                             VStep<L, NLEV, TH>::prime_last(cur, tail[pl]);
                         } else {
-                            const uint32_t lane_off = (uint32_t)(2 * pl) * band + (uint32_t)t;
+                            // byte offsets of this lane inside the plane's 4-band block (< 2^32, host check)
+                            const uint32_t off_lo = ((uint32_t)(2 * pl) * band + (uint32_t)t) * (uint32_t)sizeof(OutT);
+                            const uint32_t off_hi = off_lo + band * (uint32_t)sizeof(OutT);
                             VStep<L, NLEV, TH>::last(cur, tail[pl], taps.lo, taps.hi, [&](int i, float a, float d) {
                                 const int y = y0 + i;
                                 if (y >= 0 && y < H) {
-                                    OutT *orow = oplane + (size_t)y * W;   // uniform
-                                    orow[lane_off] = (OutT)a;
-                                    orow[lane_off + band] = (OutT)d;
+                                    OutT *orow = oplane + (size_t)y * W;   // uniform: lives in an SGPR pair
+                                    store_row(orow, off_lo, (OutT)a);
+                                    store_row(orow, off_hi, (OutT)d);
                                 }
                             });
                         }
