@@ -133,7 +133,8 @@ struct Hist {
 template <typename Source, bool U16, bool STAGED>
 __device__ __forceinline__ void rank_one_query(const Source &src, int64_t n_items, int C, int nbins,
                                                int k, int32_t *__restrict__ idx_out,
-                                               uint8_t *__restrict__ dist_out, uint32_t *lds)
+                                               uint8_t *__restrict__ dist_out, uint32_t *lds,
+                                               uint32_t *__restrict__ cum_out = nullptr)
 {
     Hist<U16> hist{lds};
     uint32_t *tot = lds + Hist<U16>::words(nbins);     // kMaxBins
@@ -241,6 +242,10 @@ __device__ __forceinline__ void rank_one_query(const Source &src, int64_t n_item
     }
     __syncthreads();
     const int T = (int)misc[0];
+    // cumulative histogram of ALL items (cum[b] = #items with distance < b): lets a sharded search derive the
+    // global threshold from one small all-reduce instead of exchanging full-length lists
+    if (cum_out)
+        for (int b = tid; b <= nbins; b += kTopkThreads) cum_out[b] = base[b];
 
     // ---- per-bin exclusive scan over threads, plus the bin base -> starting output offsets
     for (int b = wv; b <= T; b += kTopkThreads / 64) {
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(kTopkThreads) void k_hamming_topk(const uint64_t *_
                                                                int32_t *__restrict__ idx,
                                                                uint8_t *__restrict__ dist, int64_t N,
                                                                int C, int nbins, int k,
-                                                               int64_t idx_offset)
+                                                               int64_t idx_offset, uint32_t *__restrict__ cum)
 {
     extern __shared__ uint4 lds4[];
     const int qi = blockIdx.x;
@@ -416,7 +421,8 @@ __global__ __launch_bounds__(kTopkThreads) void k_hamming_topk(const uint64_t *_
 #pragma unroll
     for (int w = 0; w < WORDS; ++w) src.qw[w] = q[(int64_t)qi * WORDS + w];
     rank_one_query<CodeSource<WORDS>, U16, STAGED>(src, N, C, nbins, k, idx + (int64_t)qi * k,
-                                           dist ? dist + (int64_t)qi * k : nullptr, reinterpret_cast<uint32_t *>(lds4));
+                                           dist ? dist + (int64_t)qi * k : nullptr, reinterpret_cast<uint32_t *>(lds4),
+                                           cum ? cum + (int64_t)qi * (nbins + 1) : nullptr);
 }
 
 template <bool U16, bool STAGED>
@@ -549,7 +555,8 @@ static int launch_transpose(const uint64_t *db, uint64_t *dbT, int64_t N, hipStr
 // dbT == nullptr: build the column image into `ws` first (one extra small launch per call)
 template <int WORDS>
 static int launch_topk(const uint64_t *q, const uint64_t *db, const uint64_t *dbT_ready, int32_t *idx, uint8_t *dist,
-                       int Q, int64_t N, int nbits, int k, int64_t idx_offset, void *ws, hipStream_t st)
+                       int Q, int64_t N, int nbits, int k, int64_t idx_offset, void *ws, hipStream_t st,
+                       uint32_t *cum = nullptr)
 {
     const int C = (int)ceil_div(N, kTopkThreads);
     const int nbins = nbits + 1;
@@ -569,7 +576,7 @@ static int launch_topk(const uint64_t *q, const uint64_t *db, const uint64_t *db
         auto kern = k_hamming_topk<WORDS, decltype(U)::value, decltype(S)::value>;
         int r0 = set_lds_attr(reinterpret_cast<const void *>(kern), lds, "hamming_topk");
         if (r0) return r0;
-        hipLaunchKernelGGL(kern, dim3(Q), dim3(kTopkThreads), lds, st, q, dbT, idx, dist, N, C, nbins, k, idx_offset);
+        hipLaunchKernelGGL(kern, dim3(Q), dim3(kTopkThreads), lds, st, q, dbT, idx, dist, N, C, nbins, k, idx_offset, cum);
         return (int)WV_OK;
     });
     if (rc) return rc;
@@ -722,4 +729,28 @@ extern "C" int wv_map_at_k(const int32_t *idx, int Q, int k, const uint64_t *qla
         hipLaunchKernelGGL((k_map_at_k<0>), dim3(Q), dim3(256), 0, st, idx, k, qlab, dblab, lwords, ap, nrel);
     WV_CHECK_LAUNCH("k_map_at_k");
     return WV_OK;
+}
+
+extern "C" int wv_hamming_topk_ex(const uint64_t *q, const uint64_t *db, const void *prepared, int32_t *idx,
+                                  uint8_t *dist, uint32_t *cum, int Q, int64_t N, int nbits, int k, int64_t idx_offset,
+                                  void *workspace, size_t workspace_bytes, void *stream)
+{
+    WV_REQUIRE(q && idx && (db || prepared), "hamming_topk_ex: null buffer");
+    WV_REQUIRE(Q >= 0 && N >= 1, "hamming_topk_ex: bad shape Q=%d N=%lld", Q, (long long)N);
+    WV_REQUIRE(nbits >= 1 && nbits <= 128, "hamming_topk_ex: nbits=%d (supported: 1..128)", nbits);
+    WV_REQUIRE(k >= 1 && k <= N, "hamming_topk_ex: k=%d must be in [1, N=%lld]", k, (long long)N);
+    WV_REQUIRE(N + idx_offset <= 0x7fffffffLL && idx_offset >= 0, "hamming_topk_ex: indices exceed int32");
+    if (Q == 0) return WV_OK;
+    const int words = (nbits + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t *dbT = nullptr;
+    if (prepared) {
+        dbT = (const uint64_t *)((const char *)prepared + align_up((int64_t)dist_prepared_bytes(N, words), 256));
+    } else {
+        const size_t need = wv_hamming_topk_workspace_bytes(Q, N, words, k);
+        if (!workspace || workspace_bytes < need)
+            WV_FAIL(WV_ENOMEM, "hamming_topk_ex: workspace %zu < %zu bytes", workspace_bytes, need);
+    }
+    if (words == 1) return launch_topk<1>(q, db, dbT, idx, dist, Q, N, nbits, k, idx_offset, workspace, st, cum);
+    return launch_topk<2>(q, db, dbT, idx, dist, Q, N, nbits, k, idx_offset, workspace, st, cum);
 }

@@ -128,10 +128,11 @@ class TopkWorkspace:
         return self.buf
 
 
-def hamming_topk(q_packed, db, nbits, k, idx_offset=0, workspace=None, want_dist=True):
+def hamming_topk(q_packed, db, nbits, k, idx_offset=0, workspace=None, want_dist=True, want_cum=False):
     """k nearest database rows per query, ascending (distance, index).
     `db`: packed int64 codes [N, words] or a PreparedDB.
-    -> (idx int32 [Q,k], dist uint8 [Q,k] or None)."""
+    -> (idx int32 [Q,k], dist uint8 [Q,k] or None)   [+ cum int32 [Q, nbits+2] when want_cum:
+    cum[q, b] = number of rows with distance < b]."""
     lib = _lib.require_gpu()
     Q, words = q_packed.shape
     prepared = isinstance(db, PreparedDB)
@@ -141,6 +142,21 @@ def hamming_topk(q_packed, db, nbits, k, idx_offset=0, workspace=None, want_dist
     dev = q_packed.device
     idx = torch.empty((Q, k), dtype=torch.int32, device=dev)
     dist = torch.empty((Q, k), dtype=torch.uint8, device=dev) if want_dist else None
+    if want_cum:
+        cum = torch.empty((Q, nbits + 2), dtype=torch.int32, device=dev)
+        db_packed = db.packed if prepared else db
+        use_prep = prepared and words <= 2
+        ws = None
+        if not use_prep:
+            ws_bytes = lib.wv_hamming_topk_workspace_bytes(Q, N, words, k)
+            ws = (workspace or TopkWorkspace()).get(ws_bytes, dev)
+        with torch.cuda.device(dev):
+            rc = lib.wv_hamming_topk_ex(_lib.ptr(q_packed), _lib.ptr(db_packed), _lib.ptr(db.blob) if use_prep else None,
+                                        _lib.ptr(idx), _lib.ptr(dist), _lib.ptr(cum), Q, N, nbits, k, idx_offset,
+                                        _lib.ptr(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0),
+                                        _lib.stream_ptr())
+            _lib.check(rc, "wv_hamming_topk_ex")
+        return idx, dist, cum
     with torch.cuda.device(dev):
         if prepared and words <= 2:
             rc = lib.wv_hamming_topk_prepared(_lib.ptr(q_packed), _lib.ptr(db.blob), _lib.ptr(idx), _lib.ptr(dist),

@@ -53,17 +53,32 @@ def pad_value(nbits):
     return nbits + 1
 
 
-def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, workspace=None):
+def _all_reduce(t, op, group):
+    if _cpu_staged(group) and t.is_cuda:
+        c = t.cpu()
+        dist.all_reduce(c, op=op, group=group)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
+def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, workspace=None, trim=True):
     """q_local: packed codes of THIS rank's queries [Ql, words]; db_shard: this rank's rows
-    [lo:hi] of the packed database.  Returns the global (idx int32 [Ql,k], dist uint8 [Ql,k]) of the
-    local queries.  Every rank must call with the same Ql."""
+    [lo:hi] of the packed database (tensor or PreparedDB).  Returns the global (idx int32 [Ql,k], dist uint8
+    [Ql,k]) of the local queries.  Every rank must call with the same Ql.
+
+    trim=True: the per-shard ranking also returns each query's cumulative distance histogram; one all-reduce
+    of it (Q*(nbits+2)*4 bytes) gives every rank the global k-th distance T of every query, a shard then only
+    has to send its list prefix with distance <= T.  The prefix length used is the maximum over all queries
+    and shards (one scalar MAX all-reduce + one host read), so the exchange stays a fixed-size all_to_all --
+    typically ~k/world + ties entries per query instead of min(k, shard rows)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return H.hamming_topk(q_local, db_shard, nbits, k, workspace=workspace)
     rank = dist.get_rank(group)
     Ql, words = q_local.shape
     lo, hi, per = shard_bounds(n_total, world, rank)
-    kin = min(k, per)                                   # list length every shard sends (padded)
+    kin = min(k, per)                                   # longest list a shard could have to send
     # 1. every rank needs every query
     q_all = torch.empty((world * Ql, words), dtype=q_local.dtype, device=q_local.device)
     _all_gather(q_all, q_local.contiguous(), group)
@@ -72,18 +87,34 @@ def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, works
     if not isinstance(db_shard, H.PreparedDB) and db_shard.shape[0] != n_local:
         raise ValueError(f"rank {rank}: shard has {db_shard.shape[0]} rows, expected rows [{lo}, {hi}) of {n_total}")
     k_local = min(kin, n_local)
-    idx_s = torch.full((world * Ql, kin), -1, dtype=torch.int32, device=q_local.device)
-    dist_s = torch.full((world * Ql, kin), pad_value(nbits), dtype=torch.uint8, device=q_local.device)
+    dev = q_local.device
+    i = d = cum = None
     if k_local > 0:
-        i, d = H.hamming_topk(q_all, db_shard, nbits, k_local, idx_offset=lo, workspace=workspace)
-        if k_local == kin:
-            idx_s, dist_s = i, d
+        if trim:
+            i, d, cum = H.hamming_topk(q_all, db_shard, nbits, k_local, idx_offset=lo, workspace=workspace,
+                                       want_cum=True)
         else:
-            idx_s[:, :k_local], dist_s[:, :k_local] = i, d
+            i, d = H.hamming_topk(q_all, db_shard, nbits, k_local, idx_offset=lo, workspace=workspace)
+    send = kin
+    if trim:
+        if cum is None:                                 # empty shard: contributes nothing
+            cum = torch.zeros((world * Ql, nbits + 2), dtype=torch.int32, device=dev)
+        cum_g = cum.clone()
+        _all_reduce(cum_g, dist.ReduceOp.SUM, group)
+        # T = first bin b with (#rows of the whole database with distance <= b) >= k
+        T = (cum_g[:, 1:] >= k).int().argmax(dim=1)
+        need = torch.gather(cum, 1, (T + 1).unsqueeze(1).long()).max().reshape(1)   # local rows with distance <= T
+        _all_reduce(need, dist.ReduceOp.MAX, group)
+        send = max(1, min(kin, int(need.item())))       # the one host read of the exchange
+    idx_s = torch.full((world * Ql, send), -1, dtype=torch.int32, device=dev)
+    dist_s = torch.full((world * Ql, send), pad_value(nbits), dtype=torch.uint8, device=dev)
+    if k_local > 0:
+        w = min(send, k_local)
+        idx_s[:, :w], dist_s[:, :w] = i[:, :w], d[:, :w]
     # 3. exchange: block j of my lists (queries of rank j) goes to rank j
     idx_r = torch.empty_like(idx_s)
     dist_r = torch.empty_like(dist_s)
-    _all_to_all(idx_r, idx_s.contiguous(), group)
-    _all_to_all(dist_r, dist_s.contiguous(), group)
-    # received layout: [shard g][my Ql queries][kin]  ->  merge
-    return H.topk_merge(idx_r.view(world, Ql, kin), dist_r.view(world, Ql, kin), k, nbits)
+    _all_to_all(idx_r, idx_s, group)
+    _all_to_all(dist_r, dist_s, group)
+    # received layout: [shard g][my Ql queries][send]  ->  merge
+    return H.topk_merge(idx_r.view(world, Ql, send), dist_r.view(world, Ql, send), k, nbits)

@@ -122,6 +122,15 @@ int wv_hamming_dist_prepared(const uint64_t *q, const void *prepared, uint8_t *d
 int wv_hamming_topk_prepared(const uint64_t *q, const void *prepared, int32_t *idx, uint8_t *dist, int Q,
                              int64_t N, int nbits, int k, int64_t idx_offset, void *stream);
 
+/* Same ranking with every option: `prepared` (or NULL) instead of / beside `db`, and `cum` (or NULL):
+ * uint32 [Q][nbits + 2], cum[q][b] = number of database rows of THIS call with distance < b (cum[q][nbits+1] = N).
+ * A row-sharded search all-reduces `cum` to learn each query's global k-th distance, and then exchanges only
+ * the list prefixes that can matter (wvhash/parallel.py) -- the role faiss' host-side shard merge plays at
+ * get_knn.py:41-44. */
+int wv_hamming_topk_ex(const uint64_t *q, const uint64_t *db, const void *prepared, int32_t *idx, uint8_t *dist,
+                       uint32_t *cum, int Q, int64_t N, int nbits, int k, int64_t idx_offset, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
 /* Merge of G per-shard top-k lists (gathered with one all-gather) into the global top-k.
  * Replaces the host-side shard merge inside faiss.index_cpu_to_all_gpus(shards=True)
  *   (get_knn.py:41-44).  Lists must come from contiguous row shards in rank order, so that

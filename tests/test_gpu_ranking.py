@@ -268,3 +268,16 @@ def test_voc_shape_16bit_full_gallery():
     m_ref, ap_ref = ranking.calculate_maphashing(q, ql, r, rl, N, stable=True, return_per_query=True)
     np.testing.assert_allclose(ap.cpu().numpy(), ap_ref, atol=AP_TOL)
     assert abs(m - m_ref) < AP_TOL
+
+
+def test_cumulative_histogram_output():
+    Q, N, nbits, k = 9, 7001, 64, 500
+    q, r = synth.random_codes(Q, N, nbits, seed=11)
+    qp, rp = H.pack_codes(q.cuda()), H.pack_codes(r.cuda())
+    for db in (rp, H.PreparedDB(rp, nbits)):
+        idx, d, cum = H.hamming_topk(qp, db, nbits, k, want_cum=True)
+        dm = ranking.hamming_matrix_u8(q, r)
+        ref = torch.stack([(dm < b).sum(1) for b in range(nbits + 2)], dim=1)
+        assert torch.equal(cum.cpu().long(), ref)
+        ri, rd = ranking.hamming_topk_stable(q, r, k)
+        assert torch.equal(idx.cpu().long(), ri) and torch.equal(d.cpu().long(), rd)

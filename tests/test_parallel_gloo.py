@@ -33,10 +33,15 @@ def _pack(codes):
     return lo + torch.where(w[..., 63] > 0, torch.tensor(-2 ** 63), torch.tensor(0))
 
 
-def _fake_topk(q_packed, db, nbits, k, idx_offset=0, workspace=None, want_dist=True):
+def _fake_topk(q_packed, db, nbits, k, idx_offset=0, workspace=None, want_dist=True, want_cum=False):
     from oracle import ranking
-    idx, d = ranking.hamming_topk_stable(_unpack(q_packed, nbits), _unpack(db, nbits), k)
-    return (idx + idx_offset).int(), d.to(torch.uint8)
+    q, r = _unpack(q_packed, nbits), _unpack(db, nbits)
+    idx, d = ranking.hamming_topk_stable(q, r, k)
+    if not want_cum:
+        return (idx + idx_offset).int(), d.to(torch.uint8)
+    dm = ranking.hamming_matrix_u8(q, r)
+    cum = torch.stack([(dm < b).sum(1) for b in range(nbits + 2)], dim=1).int()   # cum[q, b] = #rows with dist < b
+    return (idx + idx_offset).int(), d.to(torch.uint8), cum
 
 
 def _fake_merge(idx_in, dist_in, k, nbits):
@@ -59,8 +64,10 @@ def _worker(rank, world, port, cases, nbits, ql, out_dir):
     for n_db, k in cases:
         q_all, r = synth.random_codes(world * ql, n_db, nbits, seed=3)
         lo, hi, _ = parallel.shard_bounds(n_db, world, rank)
-        idx, d = parallel.sharded_hamming_topk(_pack(q_all[rank * ql:(rank + 1) * ql]), _pack(r[lo:hi]), nbits, k, n_db)
-        out[(n_db, k)] = (idx, d)
+        for trim in (True, False):      # histogram-trimmed exchange and full-length exchange must agree
+            idx, d = parallel.sharded_hamming_topk(_pack(q_all[rank * ql:(rank + 1) * ql]), _pack(r[lo:hi]), nbits,
+                                                   k, n_db, trim=trim)
+            out[(n_db, k, trim)] = (idx, d)
     torch.save(out, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -81,8 +88,9 @@ def test_sharded_topk_equals_unsharded(tmp_path, world, cases):
             q_all, r = synth.random_codes(world * ql, n_db, nbits, seed=3)
             ref_idx, ref_d = ranking.hamming_topk_stable(q_all, r, k)
             sl = slice(rank * ql, (rank + 1) * ql)
-            assert torch.equal(got[(n_db, k)][0].long(), ref_idx[sl]), (world, rank, n_db, k)
-            assert torch.equal(got[(n_db, k)][1].long(), ref_d[sl])
+            for trim in (True, False):
+                assert torch.equal(got[(n_db, k, trim)][0].long(), ref_idx[sl]), (world, rank, n_db, k, trim)
+                assert torch.equal(got[(n_db, k, trim)][1].long(), ref_d[sl])
 
 
 def test_pack_unpack_helpers_match_oracle_layout():
