@@ -57,25 +57,6 @@ struct CodeSource {
     __device__ __forceinline__ int32_t id(int64_t item) const { return (int32_t)(item + idx_offset); }
 };
 
-// ListSource: items are entries of G gathered per-shard lists for this query, in (shard, position)
-// order; distance and id are read back.
-struct ListSource {
-    const uint8_t *dist_q;   // + (g * Q + qi) * kin + p  handled by strides below
-    const int32_t *idx_q;
-    int64_t shard_stride;    // Q * kin
-    int64_t n;               // G * kin (items past n read as 0 and are never counted)
-    int kin;
-    __device__ __forceinline__ int64_t addr(int64_t item) const
-    {
-        const int64_t g = item / kin;
-        return g * shard_stride + (item - g * kin);
-    }
-    using Raw = int;
-    __device__ __forceinline__ Raw fetch(int, int, int64_t item) const { return item < n ? dist_q[addr(item)] : 0; }
-    __device__ __forceinline__ int dist(const Raw &c) const { return c; }
-    __device__ __forceinline__ int32_t id(int64_t item) const { return idx_q[addr(item)]; }
-};
-
 // RowSource: items are the entries of one stored distance-matrix row
 struct RowSource {
     const uint8_t *row;
@@ -426,26 +407,6 @@ __global__ __launch_bounds__(kTopkThreads) void k_hamming_topk(const uint64_t *_
 }
 
 template <bool U16, bool STAGED>
-__global__ __launch_bounds__(kTopkThreads) void k_topk_merge(const int32_t *__restrict__ idx_in,
-                                                             const uint8_t *__restrict__ dist_in,
-                                                             int G, int Q, int kin,
-                                                             int32_t *__restrict__ idx_out,
-                                                             uint8_t *__restrict__ dist_out, int k,
-                                                             int C, int nbins)
-{
-    extern __shared__ uint4 lds4[];
-    const int qi = blockIdx.x;
-    ListSource src;
-    src.dist_q = dist_in + (int64_t)qi * kin;
-    src.idx_q = idx_in + (int64_t)qi * kin;
-    src.shard_stride = (int64_t)Q * kin;
-    src.n = (int64_t)G * kin;
-    src.kin = kin;
-    rank_one_query<ListSource, U16, STAGED>(src, (int64_t)G * kin, C, nbins, k, idx_out + (int64_t)qi * k,
-                                    dist_out ? dist_out + (int64_t)qi * k : nullptr, reinterpret_cast<uint32_t *>(lds4));
-}
-
-template <bool U16, bool STAGED>
 __global__ __launch_bounds__(kTopkThreads) void k_rank_from_dist(const uint8_t *__restrict__ dmat,
                                                                  int64_t ld, int64_t N,
                                                                  int32_t *__restrict__ idx,
@@ -459,6 +420,76 @@ __global__ __launch_bounds__(kTopkThreads) void k_rank_from_dist(const uint8_t *
     src.n = N;
     rank_one_query<RowSource, U16, STAGED>(src, N, C, nbins, k, idx + (int64_t)qi * k, dist ? dist + (int64_t)qi * k : nullptr,
                                    reinterpret_cast<uint32_t *>(lds4));
+}
+
+// ------------------------------------------------------------------------ merge of sorted shard lists
+// The G input lists of a query are each sorted by (distance, index) and come from contiguous row shards in
+// rank order, so the merged order is: by distance bin, then by shard, then by position inside the shard's
+// run of that distance.  Run boundaries come from binary searches on the sorted distance rows (no per-item
+// histogram, no atomics); every entry's output position is  p + delta[g][d]  with one LDS lookup, entries are
+// read in coalesced order and land in contiguous runs.
+__global__ __launch_bounds__(256) void k_merge_sorted(const int32_t *__restrict__ idx_in,
+                                                      const uint8_t *__restrict__ dist_in, int G, int Q, int kin,
+                                                      int32_t *__restrict__ idx_out,
+                                                      uint8_t *__restrict__ dist_out, int k, int nbins)
+{
+    extern __shared__ uint4 lds4[];
+    int32_t *start = reinterpret_cast<int32_t *>(lds4);           // [G][nbins + 1]: first position with dist >= b
+    int32_t *delta = start + G * (nbins + 1);                     // [G][nbins]
+    uint32_t *base = reinterpret_cast<uint32_t *>(delta + G * nbins);   // [nbins + 1]
+    const int qi = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int64_t shard_stride = (int64_t)Q * kin;
+    const uint8_t *dq = dist_in + (int64_t)qi * kin;
+    const int32_t *iq = idx_in + (int64_t)qi * kin;
+
+    for (int u = tid; u < G * (nbins + 1); u += 256) {
+        const int g = u / (nbins + 1), b = u - g * (nbins + 1);
+        const uint8_t *row = dq + g * shard_stride;
+        int lo = 0, hi = kin;                                     // first p with row[p] >= b
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((int)row[mid] < b) lo = mid + 1;
+            else hi = mid;
+        }
+        start[u] = lo;
+    }
+    __syncthreads();
+    if (wv == 0) {   // totals per bin and their exclusive scan (up to 3 bins per lane)
+        uint32_t t[3] = {0, 0, 0};
+        const int b0 = 3 * lane;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (b0 + j < nbins)
+                for (int g = 0; g < G; ++g) t[j] += (uint32_t)(start[g * (nbins + 1) + b0 + j + 1] - start[g * (nbins + 1) + b0 + j]);
+        const uint32_t incl = wave_incl_scan_u32(t[0] + t[1] + t[2]);
+        const uint32_t excl = incl - (t[0] + t[1] + t[2]);
+        if (b0 < nbins) base[b0] = excl;
+        if (b0 + 1 < nbins) base[b0 + 1] = excl + t[0];
+        if (b0 + 2 < nbins) base[b0 + 2] = excl + t[0] + t[1];
+    }
+    __syncthreads();
+    for (int b = tid; b < nbins; b += 256) {
+        uint32_t run = base[b];
+        for (int g = 0; g < G; ++g) {
+            const int s0 = start[g * (nbins + 1) + b], s1 = start[g * (nbins + 1) + b + 1];
+            delta[g * nbins + b] = (int32_t)run - s0;
+            run += (uint32_t)(s1 - s0);
+        }
+    }
+    __syncthreads();
+    for (int g = 0; g < G; ++g) {
+        const uint8_t *row = dq + g * shard_stride;
+        const int32_t *irow = iq + g * shard_stride;
+        for (int p = tid; p < kin; p += 256) {
+            const int d = row[p];
+            if (d >= nbins) continue;                             // defensive: not a bin this call was sized for
+            const int pos = p + delta[g * nbins + d];
+            if (pos < k) {
+                idx_out[(int64_t)qi * k + pos] = irow[p];
+                if (dist_out) dist_out[(int64_t)qi * k + pos] = (uint8_t)d;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------ average precision
@@ -671,21 +702,12 @@ extern "C" int wv_topk_merge(const int32_t *idx_in, const uint8_t *dist_in, int 
     WV_REQUIRE(nbits >= 1 && nbits <= 128, "topk_merge: nbits=%d (supported: 1..128)", nbits);
     WV_REQUIRE(k >= 1 && (int64_t)k <= (int64_t)G * kin, "topk_merge: k=%d > G*kin", k);
     if (Q == 0) return WV_OK;
-    const int64_t items = (int64_t)G * kin;
-    const int C = (int)ceil_div(items, kTopkThreads);
     const int nbins = nbits + 2;  // dist = nbits + 1 marks padding entries: they rank after every real one
-    const bool u16 = rank_u16(items), staged = rank_staged(k, nbins, u16);
-    const size_t lds = rank_lds_bytes(nbins, u16, k);
-    int rc = dispatch_rank(u16, staged, [&](auto U, auto S) {
-        auto kern = k_topk_merge<decltype(U)::value, decltype(S)::value>;
-        int r0 = set_lds_attr(reinterpret_cast<const void *>(kern), lds, "topk_merge");
-        if (r0) return r0;
-        hipLaunchKernelGGL(kern, dim3(Q), dim3(kTopkThreads), lds, (hipStream_t)stream, idx_in, dist_in, G, Q, kin,
-                           idx_out, dist_out, k, C, nbins);
-        return (int)WV_OK;
-    });
-    if (rc) return rc;
-    WV_CHECK_LAUNCH("k_topk_merge");
+    const size_t lds = ((size_t)G * (nbins + 1) + (size_t)G * nbins + nbins + 1 + 4) * 4;
+    WV_REQUIRE(lds <= 60 * 1024, "topk_merge: too many shards (G=%d)", G);
+    hipLaunchKernelGGL(k_merge_sorted, dim3(Q), dim3(256), lds, (hipStream_t)stream, idx_in, dist_in, G, Q, kin,
+                       idx_out, dist_out, k, nbins);
+    WV_CHECK_LAUNCH("k_merge_sorted");
     return WV_OK;
 }
 

@@ -140,18 +140,16 @@ def test_topk_merge_of_row_shards_equals_unsharded():
     q, r = synth.random_codes(Q, N, nbits, seed=5)
     qp, rp = H.pack_codes(q.cuda()), H.pack_codes(r.cuda())
     full_idx, full_d = H.hamming_topk(qp, rp, nbits, k)
-    for G in (2, 3, 8):
+    for G in (2, 3, 7, 8):                               # 7: ragged last shard (padded lists)
         per = (N + G - 1) // G
         kin = min(k, per)
         idxs = torch.full((G, Q, kin), -1, dtype=torch.int32, device="cuda")
-        ds = torch.full((G, Q, kin), 255, dtype=torch.uint8, device="cuda")
+        ds = torch.full((G, Q, kin), nbits + 1, dtype=torch.uint8, device="cuda")   # padding of short shards
         for g in range(G):
             lo, hi = g * per, min(N, (g + 1) * per)
             kk = min(kin, hi - lo)
             i, d = H.hamming_topk(qp, rp[lo:hi].contiguous(), nbits, kk, idx_offset=lo)
             idxs[g, :, :kk], ds[g, :, :kk] = i, d
-        if (idxs < 0).any():
-            continue  # ragged last shard smaller than kin: handled by the padded path in wvhash.parallel
         mi, md = H.topk_merge(idxs, ds, k, nbits)
         assert torch.equal(mi, full_idx) and torch.equal(md, full_d)
 

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Single-GPU timing of the per-rank ranking work of the N-way sharded search (what one of N ranks does)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "image-retrieval-wavelet_amd"))
+import torch
+from wvhash import synth
+from wvhash.engine import hamming as H
+
+def timeit(fn, reps=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+N_DB, K, QL = 25000, 5000, 2048
+for world in (1, 2, 4, 8):
+    per = (N_DB + world - 1) // world
+    q, r = synth.random_codes(world * QL, per, 64, seed=world)
+    qp = H.pack_codes(q.cuda()); prep = H.PreparedDB(H.pack_codes(r.cuda()), 64)
+    kl = min(K, per)
+    t_local = timeit(lambda: H.hamming_topk(qp, prep, 64, kl, want_cum=True))
+    send = min(kl, int(K / world * 1.6) + 64)
+    idx = torch.randint(0, N_DB, (world, QL, send), dtype=torch.int32, device="cuda")
+    d = torch.sort(torch.randint(20, 40, (world, QL, send), dtype=torch.uint8, device="cuda"), dim=2).values
+    t_merge = timeit(lambda: H.topk_merge(idx, d, min(K, world * send), 64)) if world > 1 else 0.0
+    mb = world * QL * send * 5 / 1e6
+    print(f"world={world}: local rank of {world*QL} queries vs {per} rows (k'={kl}): {t_local*1e3:.0f} us | "
+          f"merge {world} x {send}: {t_merge*1e3:.0f} us | lists sent per rank ~{mb:.0f} MB", flush=True)
