@@ -296,7 +296,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (SWT, head) / u64 popcount (ranking)", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic",
         "map_at_5000": round(map_at_k, 6),
         "config": {
             "workload": "c1: MIRFLICKR-25k shape, retrieval-only: per GPU per step 2048 query images "
@@ -305,6 +305,8 @@ def main():
                         "codes -> mAP@5000",
             "queries_per_gpu": args.queries, "db_codes": N_DB, "nbits": NBITS, "k": TOPK,
             "wavelet": WAVELET, "level": LEVEL,
+            "arithmetic": "fp32 SWT and head (fp32 MFMA), 64-bit popcount ranking, AP in fp32/fp64",
+            "streams": args.streams,
             "parallelism": f"db row-sharded x{world}, all_gather(codes)+all_to_all(top-k lists)" if world > 1 else "single GPU",
         },
     }
