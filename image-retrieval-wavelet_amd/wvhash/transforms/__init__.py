@@ -1,6 +1,6 @@
 from .custom_transforms import SWTTransform, DWTTransform, RawStackTransform, BaseWaveletTransform
-from .functional import swt2d, rawstack
+from .functional import swt2d, dwt2d, rawstack
 from .wavelets import get_filters, wavelist
 
 __all__ = ["SWTTransform", "DWTTransform", "RawStackTransform", "BaseWaveletTransform", "swt2d",
-           "rawstack", "get_filters", "wavelist"]
+           "dwt2d", "rawstack", "get_filters", "wavelist"]

@@ -93,18 +93,15 @@ class RawStackTransform(BaseWaveletTransform):
 
 
 class DWTTransform(BaseWaveletTransform):
-    """Discrete multi-level wavelet transform (size divided by 2^level).
-
-    Not part of the accelerated path yet (decimated ``pywt.wavedec2`` with
-    symmetric extension).  Constructible so that old YAMLs resolve; calling it raises.
-    """
+    """Discrete multi-level wavelet transform (size divided by 2^level): the coarsest-level bands of
+    ``pywt.wavedec2`` with PyWavelets' default symmetric extension (a plain, untuned kernel: this
+    transform is outside the hot path)."""
 
     def __init__(self, level=1, wavelet='haar', defer=False, device=None):
         super().__init__(level=level, wavelet=wavelet, defer=defer, device=device)
 
     def apply_batch(self, batch, channels_last=False):
-        raise NotImplementedError("DWTTransform (decimated wavedec2) is not implemented in wvhash yet; "
-                                  "use SWTTransform (the hot path) or the reference transform")
+        return F.dwt2d(batch, self.wavelet, self.level, channels_last=channels_last)
 
     def __repr__(self):
         factor = 2 ** self.level

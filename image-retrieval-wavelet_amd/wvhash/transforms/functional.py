@@ -67,6 +67,29 @@ def swt2d(x, wavelet="haar", level=1, channels_last=False, out_dtype=torch.float
     return out
 
 
+def dwt2d(x, wavelet="haar", level=1, channels_last=False):
+    """Batch of images on the GPU -> [B, C, 4, H', W'] coarsest-level bands of the decimated DWT
+    (``pywt.wavedec2(..., mode='symmetric')``, DWTTransform at custom_transforms.py:197-201)."""
+    lib = _lib.require_gpu()
+    if not x.is_cuda:
+        raise ValueError("dwt2d: input must live on the GPU (no CPU path in the product)")
+    x = x.contiguous()
+    layout, B, C, H, W = _layout_and_shape(x, channels_last)
+    lo, hi = get_filters(wavelet)
+    Hn, Wn = lib.wv_dwt_out_len(H, len(lo), level), lib.wv_dwt_out_len(W, len(lo), level)
+    out = torch.empty((B, C, 4, Hn, Wn), dtype=torch.float32, device=x.device)
+    if B == 0:
+        return out
+    ws_bytes = lib.wv_dwt2d_workspace_bytes(B, C, H, W, level, len(lo))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.wv_dwt2d_forward(_lib.ptr(x), _in_dtype(x), layout, _lib.ptr(out), B, C, H, W, level,
+                                  _lib.host_floats(lo), _lib.host_floats(hi), len(lo), _lib.ptr(ws),
+                                  ctypes.c_size_t(ws_bytes), _lib.stream_ptr())
+        _lib.check(rc, "wv_dwt2d_forward")
+    return out
+
+
 def rawstack(x, copies=4, channels_last=False):
     """[B,C,H,W] -> [B,C,copies,H,W] identical planes (RawStackTransform, :172-188)."""
     lib = _lib.require_gpu()

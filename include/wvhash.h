@@ -67,6 +67,15 @@ int wv_swt2d_forward(const void *in, int in_dtype, int in_layout, void *out, int
 int wv_rawstack_forward(const void *in, int in_dtype, int in_layout, void *out, int out_dtype,
                         int B, int C, int H, int W, int copies, void *stream);
 
+/* Decimated multi-level 2-D DWT (DWTTransform, custom_transforms.py:191-205 -> pywt.wavedec2, mode
+ * 'symmetric'): the four bands (cA, cH, cV, cD) of the coarsest level.
+ * out: float32 [B][C][4][Hn][Wn] with Hn = wv_dwt_out_len(H, flen, level) (each level: floor((n + flen - 1) / 2)). */
+int wv_dwt_out_len(int n, int flen, int level);
+size_t wv_dwt2d_workspace_bytes(int B, int C, int H, int W, int level, int flen);
+int wv_dwt2d_forward(const void *in, int in_dtype, int in_layout, float *out, int B, int C, int H, int W,
+                     int level, const float *dec_lo, const float *dec_hi, int flen, void *workspace,
+                     size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Bit packing of +-1 hash codes and multi-hot labels.
  * Codes come out of torch.sign(logits) (multi_dino_attention.py:833) as fp32 in {-1,+1};

@@ -97,6 +97,40 @@ def swt2_level_n(plane, wavelet, level, dtype=np.float32):
     return np.stack([aa, da, ad, dd])
 
 
+def dwt_axis(x, f, axis, dtype=np.float32):
+    """One decimating pass, PyWavelets mode 'symmetric':  y[o] = sum_j f[j] * x_ext[2o + 1 - j],
+    o = 0 .. floor((N + F - 1) / 2) - 1, half-sample symmetric extension (x[-1] = x[0], x[N] = x[N-1], ...).
+    (pywt/_extensions/c/convolution.template.c: downsampling_convolution, step 2.)  Parity unpinned against
+    PyWavelets itself, like the SWT restatement."""
+    x = np.moveaxis(np.asarray(x, dtype=dtype), axis, 0)
+    f = np.asarray(f, dtype=dtype)
+    n, F = x.shape[0], f.shape[0]
+    no = (n + F - 1) // 2
+    period = 2 * n
+    out = np.zeros((no,) + x.shape[1:], dtype=dtype)
+    for o in range(no):
+        acc = np.zeros(x.shape[1:], dtype=dtype)
+        for j in range(F):
+            i = (2 * o + 1 - j) % period
+            i = i if i < n else period - 1 - i
+            acc = acc + f[j] * x[i]
+        out[o] = acc
+    return np.moveaxis(out, 0, axis)
+
+
+def wavedec2_coarsest(plane, wavelet, level, dtype=np.float32):
+    """(cA_n, cH_n, cV_n, cD_n) stacked [4, H', W'] -- what DWTTransform._apply_wavelet returns
+    (custom_transforms.py:197-201)."""
+    lo, hi = filters(wavelet)
+    a = np.asarray(plane, dtype=dtype)
+    for _ in range(level):
+        ta, td = dwt_axis(a, lo, 0, dtype), dwt_axis(a, hi, 0, dtype)
+        aa, ad = dwt_axis(ta, lo, 1, dtype), dwt_axis(ta, hi, 1, dtype)
+        da, dd = dwt_axis(td, lo, 1, dtype), dwt_axis(td, hi, 1, dtype)
+        a = aa
+    return np.stack([aa, da, ad, dd])
+
+
 def fix_size_shape(w, h, level):
     factor = 2 ** level
     return int(np.ceil(w / factor) * factor), int(np.ceil(h / factor) * factor)
