@@ -68,7 +68,9 @@ class Pipeline:
         self.bands = torch.empty((Q, 3, 4, H, W), dtype=torch.float32, device=device)
         g = torch.Generator(device="cpu").manual_seed(1234 + rank)
         self.images = torch.randint(0, 256, (Q, H, W, 3), generator=g, dtype=torch.uint8).to(device)
-        self.feats = [f.to(device) for f in synth.band_features(Q, EMBED, seed=100 + rank)]
+        # the four backbones' CLS features, resident as slices of one [4, Q, E] buffer (what a pipeline that hands
+        # each backbone an output slice produces): the head reads them in place
+        self.feats = list(torch.stack(synth.band_features(Q, EMBED, seed=100 + rank)).to(device).unbind(0))
         self.head = get_fusion_head({"type": "cross_attention_advanced", "output_dim": EMBED,
                                      "num_heads": HEADS, "num_queries": NQ, "sub_band_dropout_p": 0,
                                      "ortho_weight": 0.1}, [EMBED] * 4)

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const float *__restrict__ A, co
                 float v = acc[a][b][e] + bs;
                 if (EPI == EPI_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                 if (EPI == EPI_ADD_ROW) v += R[row * N + col];
-                if (EPI == EPI_ADD_BCAST) v += R[(row % rmod) * N + col];
+                if (EPI == EPI_ADD_BCAST) v += R[(int64_t)((uint32_t)row % (uint32_t)rmod) * N + col];   // rows < 2^31 (host check)
                 C[row * N + col] = v;
             }
         }
@@ -192,10 +192,176 @@ __global__ __launch_bounds__(256, 2) void k_gemm_lds(const float *__restrict__ A
                 float v = acc[a][b][e] + bsv;
                 if (EPI == EPI_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                 if (EPI == EPI_ADD_ROW) v += R[row * N + col];
-                if (EPI == EPI_ADD_BCAST) v += R[(row % rmod) * N + col];
+                if (EPI == EPI_ADD_BCAST) v += R[(int64_t)((uint32_t)row % (uint32_t)rmod) * N + col];   // rows < 2^31 (host check)
                 C[row * N + col] = v;
             }
         }
+}
+
+// Row-panel variant: block tile 128 x 96, 4 waves stacked along M, wave tile 32 x 96 = three independent 32 x 32
+// accumulators (enough to keep the matrix pipe issuing back to back from ONE wave per SIMD).  The head's products
+// have M = 8192 rows and N in {384, 768, 1536}: M*N/1024 MFMA tiles = 3, 6, 12 per SIMD of the chip, so a 128 x 96
+// block tile gives exactly 256 / 512 / 1024 workgroups -- whole multiples of the 256 CUs, where 128 x 64 tiles
+// left a quarter of the chip idle.  K step BK (32 or 64), two LDS stages, same k <-> (step, lane half) bijection
+// and the same padded conflict-free rows as k_gemm_lds.
+template <int BK, int EPI>
+// Split K (gridDim.z > 1, EPI_NONE only): slice z covers k in [z*kchunk, (z+1)*kchunk) and writes its partial
+// product to C + z*M*N (bias in slice 0); the consumer (k_layernorm) adds the slices in index order.
+__global__ __launch_bounds__(256, 2) void k_gemm_panel(const float *__restrict__ A, const float *__restrict__ W,
+                                                    const float *__restrict__ bias, const float *__restrict__ R,
+                                                    int rmod, float *__restrict__ C, int M, int N, int K, int kchunk)
+{
+    constexpr int BM = 128, BN = 96, LDP = BK + 4;
+    {
+        const int z = blockIdx.z;
+        A += (size_t)z * kchunk;
+        W += (size_t)z * kchunk;
+        C += (size_t)z * M * N;
+        if (z) bias = nullptr;
+    }
+    constexpr int A4 = BM * (BK / 4) / 256, B4 = BN * (BK / 4) / 256;   // float4 loads per thread per stage
+    constexpr int CPR = BK / 4;                                         // float4 chunks per row
+    extern __shared__ float4 gsm4[];
+    float *sm = reinterpret_cast<float *>(gsm4);
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int r = lane & 31, h = lane >> 5;
+    // Workgroups are dealt to the 8 XCDs round-robin and each XCD has its own L2: give XCD k the k-th contiguous
+    // eighth of the tile list (column panel fastest), so the panels that share a row block of A -- and the row
+    // blocks that share W -- meet in one L2 instead of being fetched once per XCD.
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int total = gridDim.x * gridDim.y;
+        if (total % 8 == 0) {
+            const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+            const int tile = (lin % 8) * (total / 8) + lin / 8;
+            by = tile / gridDim.x;
+            bx = tile - by * gridDim.x;
+        }
+    }
+    const int64_t m0 = (int64_t)by * BM, n0 = (int64_t)bx * BN;
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+
+    f32x4 ra[A4], rb[B4];
+    const float *ga[A4], *gb[B4];
+    int so_a[A4], so_b[B4];
+#pragma unroll
+    for (int i = 0; i < A4; ++i) {
+        const int ch = i * 256 + tid, row = ch / CPR, c4 = ch % CPR;
+        ga[i] = A + min(m0 + row, (int64_t)M - 1) * K + 4 * c4;
+        so_a[i] = row * LDP + 4 * c4;
+    }
+#pragma unroll
+    for (int i = 0; i < B4; ++i) {
+        const int ch = i * 256 + tid, row = ch / CPR, c4 = ch % CPR;
+        gb[i] = W + min(n0 + row, (int64_t)N - 1) * K + 4 * c4;
+        so_b[i] = BM * LDP + row * LDP + 4 * c4;
+    }
+    constexpr int STAGE = (BM + BN) * LDP;
+#pragma unroll
+    for (int i = 0; i < A4; ++i) ra[i] = *reinterpret_cast<const f32x4 *>(ga[i]);
+#pragma unroll
+    for (int i = 0; i < B4; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(gb[i]);
+#pragma unroll
+    for (int i = 0; i < A4; ++i) *reinterpret_cast<f32x4 *>(sm + so_a[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B4; ++i) *reinterpret_cast<f32x4 *>(sm + so_b[i]) = rb[i];
+    __syncthreads();
+    const int nk = kchunk / BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        float *cur = sm + (kt & 1) * STAGE;
+        float *nxt = sm + ((kt & 1) ^ 1) * STAGE;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            const int k0 = (kt + 1) * BK;
+#pragma unroll
+            for (int i = 0; i < A4; ++i) ra[i] = *reinterpret_cast<const f32x4 *>(ga[i] + k0);
+#pragma unroll
+            for (int i = 0; i < B4; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(gb[i] + k0);
+        }
+        const float *as = cur + (wv * 32 + r) * LDP + 4 * h;
+        const float *bs = cur + BM * LDP + r * LDP + 4 * h;
+        // fragments of chunk c+1 are read from LDS before the MFMAs of chunk c are issued
+        f32x4 av_n = *reinterpret_cast<const f32x4 *>(as), bv_n[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) bv_n[b] = *reinterpret_cast<const f32x4 *>(bs + b * 32 * LDP);
+#pragma unroll
+        for (int c = 0; c < BK / 8; ++c) {
+            const f32x4 av = av_n;
+            f32x4 bv[3];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) bv[b] = bv_n[b];
+            if (c + 1 < BK / 8) {
+                av_n = *reinterpret_cast<const f32x4 *>(as + 8 * (c + 1));
+#pragma unroll
+                for (int b = 0; b < 3; ++b) bv_n[b] = *reinterpret_cast<const f32x4 *>(bs + b * 32 * LDP + 8 * (c + 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the reads above the MFMAs (the scheduler sinks them otherwise)
+            // k-major over the three accumulators: consecutive MFMAs are independent
+#pragma unroll
+            for (int b = 0; b < 3; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[b].x, acc[b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[b].y, acc[b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv[b].z, acc[b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[b].w, acc[b], 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < A4; ++i) *reinterpret_cast<f32x4 *>(nxt + so_a[i]) = ra[i];
+#pragma unroll
+            for (int i = 0; i < B4; ++i) *reinterpret_cast<f32x4 *>(nxt + so_b[i]) = rb[i];
+        }
+        __syncthreads();
+    }
+    if (m0 + BM <= M && n0 + BN <= N) {
+        // interior tile: no bounds checks, so all residual loads of an accumulator are in flight together
+        // (the guarded form below waits for each load before it issues the next)
+        const int64_t row0 = m0 + wv * 32 + 4 * h;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int64_t col = n0 + b * 32 + r;
+            const float bsv = bias ? bias[col] : 0.f;
+            float res[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
+                if (EPI == EPI_ADD_ROW) res[e] = R[row * N + col];
+                else if (EPI == EPI_ADD_BCAST) res[e] = R[(int64_t)((uint32_t)row % (uint32_t)rmod) * N + col];
+                else res[e] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
+                float v = acc[b][e] + bsv;
+                if (EPI == EPI_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                if (EPI == EPI_ADD_ROW || EPI == EPI_ADD_BCAST) v += res[e];
+                C[row * N + col] = v;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const int64_t col = n0 + b * 32 + r;
+        if (col >= N) continue;
+        const float bsv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int64_t row = m0 + wv * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (row >= M) continue;
+            float v = acc[b][e] + bsv;
+            if (EPI == EPI_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            if (EPI == EPI_ADD_ROW) v += R[row * N + col];
+            if (EPI == EPI_ADD_BCAST) v += R[(int64_t)((uint32_t)row % (uint32_t)rmod) * N + col];   // rows < 2^31 (host check)
+            C[row * N + col] = v;
+        }
+    }
 }
 
 // Softmax over the S band tokens and the context vectors, one workgroup per sample.
@@ -207,22 +373,36 @@ __global__ __launch_bounds__(256) void k_attn_core(const float *__restrict__ Qp,
                                                    float *__restrict__ ctx, int B, int E, int heads,
                                                    int Nq, int S)
 {
-    extern __shared__ float sm[];  // P[Nq][heads][S]
+    // LDS: kv[S][2E + 4] (the sample's K | V rows, fetched once with coalesced 16-byte loads) | q[Nq][E] | P[Nq][heads][S]
+    extern __shared__ float4 sm4[];
+    float *kv = reinterpret_cast<float *>(sm4);
+    const int KP = 2 * E + 4;
+    float *q = kv + (size_t)S * KP;
+    float *P = q + (size_t)Nq * E;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int hd = E / heads;
     const float scale = 1.0f / sqrtf((float)hd);
+    const int row4 = 2 * E / 4;
+    for (int t = tid; t < S * row4; t += blockDim.x) {
+        const int s = t / row4, c = t - s * row4;
+        *reinterpret_cast<float4 *>(kv + (size_t)s * KP + 4 * c) =
+            *reinterpret_cast<const float4 *>(KV + ((size_t)s * B + b) * 2 * E + 4 * c);
+    }
+    for (int t = tid; t < Nq * E / 4; t += blockDim.x)
+        *reinterpret_cast<float4 *>(q + 4 * t) = *reinterpret_cast<const float4 *>(Qp + 4 * t);
+    __syncthreads();
     const int ndots = Nq * heads * S;
     for (int t = tid; t < ndots; t += blockDim.x) {
         const int s = t % S, hh = (t / S) % heads, i = t / (S * heads);
-        const float *qv = Qp + (size_t)i * E + hh * hd;
-        const float *kv = KV + ((size_t)s * B + b) * 2 * E + hh * hd;
+        const float *qv = q + (size_t)i * E + hh * hd;
+        const float *kr = kv + (size_t)s * KP + hh * hd;
         float acc = 0.f;
-        for (int d = 0; d < hd; ++d) acc = fmaf(qv[d], kv[d], acc);
-        sm[t] = acc * scale;
+        for (int d = 0; d < hd; ++d) acc = fmaf(qv[d], kr[d], acc);
+        P[t] = acc * scale;
     }
     __syncthreads();
     for (int t = tid; t < Nq * heads; t += blockDim.x) {
-        float *p = sm + (size_t)t * S;
+        float *p = P + (size_t)t * S;
         float mx = p[0];
         for (int s = 1; s < S; ++s) mx = fmaxf(mx, p[s]);
         float sum = 0.f;
@@ -235,37 +415,97 @@ __global__ __launch_bounds__(256) void k_attn_core(const float *__restrict__ Qp,
     __syncthreads();
     for (int t = tid; t < Nq * E; t += blockDim.x) {
         const int e = t % E, i = t / E, hh = e / hd;
-        const float *p = sm + ((size_t)i * heads + hh) * S;
+        const float *p = P + ((size_t)i * heads + hh) * S;
         float acc = 0.f;
-        for (int s = 0; s < S; ++s) acc = fmaf(p[s], KV[((size_t)s * B + b) * 2 * E + E + e], acc);
+        for (int s = 0; s < S; ++s) acc = fmaf(p[s], kv[(size_t)s * KP + E + e], acc);
         ctx[((size_t)b * Nq + i) * E + e] = acc;
     }
 }
 
 // y = LayerNorm(x) over rows of length E (one wave per row), optional mean over groups of `pool`
 // consecutive rows afterwards is handled by k_mean_rows.
+// nparts > 1: x is the sum of nparts [rows][E] slices (split-K partials of the read-out product), added in
+// slice order.  Rows of up to 64*NV floats are held in registers between the three passes.
+template <int NV>
 __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, const float *__restrict__ w,
                                                    const float *__restrict__ bvec, float *__restrict__ y,
-                                                   int64_t rows, int E, float eps)
+                                                   int64_t rows, int E, float eps, int nparts)
 {
     const int lane = lane_id();
     const int64_t row = (int64_t)blockIdx.x * 4 + wave_id();
     if (row >= rows) return;
     const float *xr = x + row * E;
+    const size_t pstride = (size_t)rows * E;
+    auto value = [&](int e) {
+        float a = xr[e];
+        for (int q = 1; q < nparts; ++q) a += xr[q * pstride + e];
+        return a;
+    };
+    float val[NV > 0 ? NV : 1];
     float s = 0.f;
-    for (int e = lane; e < E; e += 64) s += xr[e];
+    if constexpr (NV > 0) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int e = lane + 64 * j;
+            val[j] = e < E ? value(e) : 0.f;
+            s += val[j];
+        }
+    } else {
+        for (int e = lane; e < E; e += 64) s += value(e);
+    }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
     const float mean = s / (float)E;
     float v = 0.f;
-    for (int e = lane; e < E; e += 64) {
-        const float dlt = xr[e] - mean;
-        v = fmaf(dlt, dlt, v);
+    if constexpr (NV > 0) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const float dlt = lane + 64 * j < E ? val[j] - mean : 0.f;
+            v = fmaf(dlt, dlt, v);
+        }
+    } else {
+        for (int e = lane; e < E; e += 64) {
+            const float dlt = value(e) - mean;
+            v = fmaf(dlt, dlt, v);
+        }
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
     const float rstd = 1.0f / sqrtf(v / (float)E + eps);
-    for (int e = lane; e < E; e += 64) y[row * E + e] = (xr[e] - mean) * rstd * w[e] + bvec[e];
+    if constexpr (NV > 0) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int e = lane + 64 * j;
+            if (e < E) y[row * E + e] = (val[j] - mean) * rstd * w[e] + bvec[e];
+        }
+    } else {
+        for (int e = lane; e < E; e += 64) y[row * E + e] = (value(e) - mean) * rstd * w[e] + bvec[e];
+    }
+}
+
+static void launch_layernorm(const float *x, const float *w, const float *b, float *y, int64_t rows, int E, float eps,
+                             int nparts, hipStream_t st)
+{
+    const dim3 grid((unsigned)ceil_div(rows, 4));
+    if (E <= 512) hipLaunchKernelGGL(k_layernorm<8>, grid, dim3(256), 0, st, x, w, b, y, rows, E, eps, nparts);
+    else if (E <= 1024) hipLaunchKernelGGL(k_layernorm<16>, grid, dim3(256), 0, st, x, w, b, y, rows, E, eps, nparts);
+    else hipLaunchKernelGGL(k_layernorm<0>, grid, dim3(256), 0, st, x, w, b, y, rows, E, eps, nparts);
+}
+
+// Batch-invariant query projection Qp[n][e] = q[n][:] . W[e][:] + b[e] (Nq <= 64 rows): one wave per output
+// element.  A matrix-core tile would be 4/32 full here.
+__global__ __launch_bounds__(256) void k_qproj(const float *__restrict__ q, const float *__restrict__ W,
+                                               const float *__restrict__ b, float *__restrict__ Qp, int Nq, int E)
+{
+    const int lane = lane_id(), o = blockIdx.x * 4 + wave_id();
+    if (o >= Nq * E) return;
+    const int n = o / E, e = o - n * E;
+    const float *wr = W + (size_t)e * E, *qr = q + (size_t)n * E;
+    float a = 0.f;
+    for (int k = lane; k < E; k += 64) a = fmaf(qr[k], wr[k], a);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) a += __shfl_xor(a, d, 64);
+    if (lane == 0) Qp[o] = a + b[e];
 }
 
 __global__ void k_mean_rows(const float *__restrict__ x, float *__restrict__ y, int64_t groups, int n, int E)
@@ -332,14 +572,46 @@ static void launch_gemm_lds(const float *A, const float *W, const float *bias, c
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, A, W, bias, R, rmod, C, M, N, K);
 }
 
+template <int BK, int EPI>
+static void launch_gemm_panel(const float *A, const float *W, const float *bias, const float *R, int rmod, float *C,
+                              int M, int N, int K, hipStream_t st, int ksplit = 1)
+{
+    constexpr size_t lds = (size_t)2 * (128 + 96) * (BK + 4) * sizeof(float);
+    auto kern = k_gemm_panel<BK, EPI>;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid((unsigned)ceil_div(N, 96), (unsigned)ceil_div(M, 128), (unsigned)ksplit);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, A, W, bias, R, rmod, C, M, N, K, K / ksplit);
+}
+
+// Slices the read-out product would be cut into (1 = no split): short-M products leave most CUs without a
+// panel, so K is cut until about every CU has one.  C must then hold that many [M][N] partials.
+static int readout_ksplit(int M, int N, int K)
+{
+    if (getenv("WV_GEMM") || K % 64 || N % 96 || M < 128) return 1;
+    const int64_t panels = ceil_div(M, 128) * ceil_div(N, 96);
+    for (int ks = 8; ks >= 2; ks >>= 1)
+        if (K % (ks * 64) == 0 && K / ks >= 128 && panels * ks <= 384) return ks;
+    return 1;
+}
+
 template <int EPI>
 static void launch_gemm(const float *A, const float *W, const float *bias, const float *R, int rmod,
                         float *C, int M, int N, int K, hipStream_t st)
 {
-    const char *force = getenv("WV_GEMM");   // "stream" pins the LDS-free kernel (tests / tuning)
+    const char *force = getenv("WV_GEMM");   // "stream" / "lds" / "panel32" / "panel64" pin a kernel (tests / tuning)
+    const int64_t panels = ceil_div(M, 128) * ceil_div(N, 96);
+    const bool panel_ok = K % 64 == 0 && N % 96 == 0 && M >= 128;
+    if (panel_ok && force && !strcmp(force, "panel32")) return launch_gemm_panel<32, EPI>(A, W, bias, R, rmod, C, M, N, K, st);
+    if (panel_ok && force && !strcmp(force, "panel64")) return launch_gemm_panel<64, EPI>(A, W, bias, R, rmod, C, M, N, K, st);
+    if (panel_ok && !force && panels >= 256) {
+        // one workgroup per CU: nothing else hides the stage hand-over, so take the long K step
+        if (panels < 512) return launch_gemm_panel<64, EPI>(A, W, bias, R, rmod, C, M, N, K, st);
+        return launch_gemm_panel<32, EPI>(A, W, bias, R, rmod, C, M, N, K, st);
+    }
     // measured on MI355X at the head's shapes: short-K, wide-N products (mlp.0: K=384, N=1536) run faster on
     // the LDS-free kernel (118 vs 142 us); everything else on the LDS-tiled one
-    const bool prefer_stream = (K <= 512 && N >= 1024) || (force && !strcmp(force, "stream"));
+    const bool prefer_stream = ((K <= 512 && N >= 1024) && !(force && !strcmp(force, "lds"))) || (force && !strcmp(force, "stream"));
     if (K % 32 == 0 && M >= 64 && !prefer_stream) {
         // largest tile that still gives every CU about two workgroups
         if (ceil_div(M, 128) * ceil_div(N, 128) >= 512) return launch_gemm_lds<128, 128, EPI>(A, W, bias, R, rmod, C, M, N, K, st);
@@ -381,7 +653,7 @@ static HeadWs carve(const wv_head_params *p, int B, void *base)
     w.hid = take(rows * 4 * E);
     w.x2 = take(rows * E);
     w.pooled = take((size_t)B * E);
-    w.pre = take((size_t)B * E);
+    w.pre = take((size_t)B * E * 8);   // up to 8 split-K partials of the read-out product
     w.bytes = off;
     return w;
 }
@@ -419,6 +691,7 @@ extern "C" int wv_band_attn_pool(const wv_head_params *p, const float *feats, in
     int rc = check_head(p, B);
     if (rc) return rc;
     WV_REQUIRE(feats && out, "band_attn_pool: null buffer");
+    WV_REQUIRE((int64_t)B * std::max(p->num_queries, p->num_tokens) < (1ll << 31), "band_attn_pool: B=%d too large", B);
     if (B == 0) return WV_OK;
     const size_t need = carve(p, B, nullptr).bytes;
     if (!workspace || workspace_bytes < need)
@@ -428,28 +701,33 @@ extern "C" int wv_band_attn_pool(const wv_head_params *p, const float *feats, in
     HeadWs w = carve(p, B, workspace);
 
     // Q projection (batch-invariant): Qp = q_eff @ Wq^T + bq
-    launch_gemm<EPI_NONE>(p->q_eff, p->in_proj_w, p->in_proj_b, nullptr, 1, w.Qp, Nq, E, E, st);
+    hipLaunchKernelGGL(k_qproj, dim3((unsigned)ceil_div(Nq * E, 4)), dim3(256), 0, st, p->q_eff, p->in_proj_w,
+                       p->in_proj_b, w.Qp, Nq, E);
     // K | V projection of all S*B tokens: rows E..3E of in_proj_weight
     launch_gemm<EPI_NONE>(feats, p->in_proj_w + (size_t)E * E, p->in_proj_b + E, nullptr, 1, w.KV, S * B, 2 * E, E, st);
-    const size_t sm = (size_t)Nq * p->num_heads * S * sizeof(float);
+    const size_t sm = ((size_t)S * (2 * E + 4) + (size_t)Nq * E + (size_t)Nq * p->num_heads * S) * sizeof(float);
+    if (sm > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn_core), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     hipLaunchKernelGGL(k_attn_core, dim3(B), dim3(256), sm, st, w.Qp, w.KV, w.ctx, B, E, p->num_heads, Nq, S);
     // x1 = q_eff + ctx @ Wo^T + bo ; x1n = LN1(x1)
     launch_gemm<EPI_ADD_BCAST>(w.ctx, p->attn_out_w, p->attn_out_b, p->q_eff, Nq, w.x1, rows, E, E, st);
-    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, w.x1, p->norm1_w,
-                       p->norm1_b, w.x1n, (int64_t)rows, E, p->ln_eps);
+    launch_layernorm(w.x1, p->norm1_w, p->norm1_b, w.x1n, (int64_t)rows, E, p->ln_eps, 1, st);
     // x2 = x1n + GELU(x1n @ W0^T + b0) @ W2^T + b2
     launch_gemm<EPI_GELU>(w.x1n, p->mlp0_w, p->mlp0_b, nullptr, 1, w.hid, rows, 4 * E, E, st);
     launch_gemm<EPI_ADD_ROW>(w.hid, p->mlp2_w, p->mlp2_b, w.x1n, 1, w.x2, rows, E, 4 * E, st);
     // read-out: concat (a [B][Nq*E] view of x2) or mean over the queries, then Linear + LN2
+    const float *ro_in = w.x2;
+    int ro_k = Nq * E;
     if (p->pool_mean) {
         hipLaunchKernelGGL(k_mean_rows, dim3((unsigned)std::min<int64_t>(ceil_div((int64_t)B * E, 256), 4096)),
                            dim3(256), 0, st, w.x2, w.pooled, (int64_t)B, Nq, E);
-        launch_gemm<EPI_NONE>(w.pooled, p->out_w, p->out_b, nullptr, 1, w.pre, B, E, E, st);
-    } else {
-        launch_gemm<EPI_NONE>(w.x2, p->out_w, p->out_b, nullptr, 1, w.pre, B, E, Nq * E, st);
+        ro_in = w.pooled;
+        ro_k = E;
     }
-    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, st, w.pre, p->norm2_w,
-                       p->norm2_b, out, (int64_t)B, E, p->ln_eps);
+    const int ks = readout_ksplit(B, E, ro_k);
+    if (ks > 1) launch_gemm_panel<64, EPI_NONE>(ro_in, p->out_w, p->out_b, nullptr, 1, w.pre, B, E, ro_k, st, ks);
+    else launch_gemm<EPI_NONE>(ro_in, p->out_w, p->out_b, nullptr, 1, w.pre, B, E, ro_k, st);
+    launch_layernorm(w.pre, p->norm2_w, p->norm2_b, out, (int64_t)B, E, p->ln_eps, ks, st);
     WV_CHECK_LAUNCH("band_attn_pool");
     return WV_OK;
 }

@@ -24,6 +24,16 @@
 #define WV_SWT_FOLD255 0
 #endif
 
+// A/B on MI355X in one session (tools/build_variant.sh), db2 level 3, 2048 images:
+//   consumer (column) waves at raised issue priority: 1.148 ms vs 1.19 ms at equal priority (they are the critical role)
+//   interior chunks storing without per-row bounds checks (a second copy of the store loop): 1.18 ms, slower -> off
+#ifndef WV_SWT_VPRIO
+#define WV_SWT_VPRIO 2
+#endif
+#ifndef WV_SWT_FASTMID
+#define WV_SWT_FASTMID 0
+#endif
+
 namespace wv {
 
 template <int L>
@@ -38,6 +48,7 @@ struct SlideGeom {
     int nrun;       // runs per row = ceil(W / R)
     int in_layout;
     int out_bf16;
+    int nxcd;       // 8: workgroups w, w+8, ... (one XCD, hardware round-robin) share images; 1: plain striding
     unsigned long long *stamps;   // diagnostic build only
 };
 
@@ -269,7 +280,12 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
     const int plane_sz = TH * P, buf_sz = 2 * plane_sz;
     const int nchunks = (H + HALO + TH - 1) / TH;         // the cascade consumes H + HALO rows per plane
     const uint32_t band = (uint32_t)H * W;
-    const int nplanes = g.B * g.C;
+    // Plane schedule.  Workgroup w runs on XCD w % 8 (round-robin dispatch) and every XCD has its own L2, so
+    // the C channel planes of one interleaved (NHWC) image -- which all read the same bytes -- go to
+    // neighbouring workgroups of ONE XCD: image b belongs to XCD b % nxcd, and the planes of an XCD's images
+    // are dealt to its workgroups in (image, channel) order.  Two of the three reads then hit that L2.
+    const int xcd = blockIdx.x % g.nxcd, wg_in_xcd = blockIdx.x / g.nxcd, wgs_per_xcd = gridDim.x / g.nxcd;
+    const int nq = g.B > xcd ? (g.B - xcd + g.nxcd - 1) / g.nxcd * g.C : 0;   // planes this XCD owns
     const bool is_h = threadIdx.x >= NH;                  // wave-uniform role
     const int t = is_h ? threadIdx.x - NH : threadIdx.x;
 
@@ -284,8 +300,8 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
         // ------------------------------------------------------------------ producer: pass H
         const int rr = t / g.nrun, j = t - rr * g.nrun;
         const bool active = t < TH * g.nrun;
-        for (int pc = blockIdx.x; pc < nplanes; pc += gridDim.x) {
-            const int b = pc / g.C, c = pc - b * g.C;
+        for (int q = wg_in_xcd; q < nq; q += wgs_per_xcd) {
+            const int m = q / g.C, c = q - m * g.C, b = xcd + g.nxcd * m, pc = b * g.C + c;
             const InT *img = LAYOUT == 0 ? in + (size_t)pc * band : in + (size_t)b * band * 3;
             Raw raw[NG];
             auto fetch = [&](int chunk) {
@@ -344,9 +360,11 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
     } else {
         // ------------------------------------------------------------------ consumer: pass V
         const bool active = t < W;
+        if (WV_SWT_VPRIO) __builtin_amdgcn_s_setprio(WV_SWT_VPRIO);   // the critical role issues first
         // this column's slot in the permuted LDS row (see pass H)
         const int tp = ((t % R) / 4) * (4 * g.nrun) + (t / R) * 4 + (t & 3);
-        for (int pc = blockIdx.x; pc < nplanes; pc += gridDim.x) {
+        for (int q = wg_in_xcd; q < nq; q += wgs_per_xcd) {
+            const int m = q / g.C, pc = (xcd + g.nxcd * m) * g.C + (q - m * g.C);
             OutT *oplane = reinterpret_cast<OutT *>(out) + (size_t)pc * 4 * band;
             float tail[2][HALO];
 #pragma unroll
@@ -370,14 +388,23 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
                             // byte offsets of this lane inside the plane's 4-band block (< 2^32, host check)
                             const uint32_t off_lo = ((uint32_t)(2 * pl) * band + (uint32_t)t) * (uint32_t)sizeof(OutT);
                             const uint32_t off_hi = off_lo + band * (uint32_t)sizeof(OutT);
-                            VStep<L, NLEV, TH>::last(cur, tail[pl], taps.lo, taps.hi, [&](int i, float a, float d) {
-                                const int y = y0 + i;
-                                if (y >= 0 && y < H) {
-                                    OutT *orow = oplane + (size_t)y * W;   // uniform: lives in an SGPR pair
+                            if (WV_SWT_FASTMID && y0 >= 0 && y0 + TH <= H) {   // interior chunk: all TH rows exist
+                                OutT *orow0 = oplane + (size_t)y0 * W;
+                                VStep<L, NLEV, TH>::last(cur, tail[pl], taps.lo, taps.hi, [&](int i, float a, float d) {
+                                    OutT *orow = orow0 + (size_t)i * W;
                                     store_row(orow, off_lo, (OutT)a);
                                     store_row(orow, off_hi, (OutT)d);
-                                }
-                            });
+                                });
+                            } else {
+                                VStep<L, NLEV, TH>::last(cur, tail[pl], taps.lo, taps.hi, [&](int i, float a, float d) {
+                                    const int y = y0 + i;
+                                    if (y >= 0 && y < H) {
+                                        OutT *orow = oplane + (size_t)y * W;   // uniform: lives in an SGPR pair
+                                        store_row(orow, off_lo, (OutT)a);
+                                        store_row(orow, off_hi, (OutT)d);
+                                    }
+                                });
+                            }
                         }
                     }
                 }
@@ -427,7 +454,11 @@ static int launch_slide(const void *in, void *out, SlideGeom g, const float *lo,
     const char *env = getenv("WV_SWT_WG_PER_CU");
     const int per_cu = env && atoi(env) > 0 ? atoi(env) : std::min(by_lds, std::max(1, MINW * 256 / (2 * NT)));
     const int64_t planes = (int64_t)g.B * g.C;
-    const int64_t grid = std::min<int64_t>(planes, (int64_t)num_cu * per_cu);
+    int64_t grid = std::min<int64_t>(planes, (int64_t)num_cu * per_cu);
+    const char *xenv = getenv("WV_SWT_XCD");
+    g.nxcd = xenv ? std::max(1, atoi(xenv)) : 8;
+    if (grid < planes) grid -= grid % g.nxcd;      // persistent launch: same number of workgroups on every XCD
+    if (grid <= 0 || grid % g.nxcd) g.nxcd = 1, grid = std::min<int64_t>(planes, (int64_t)num_cu * per_cu);
     if (getenv("WV_SWT_STAMPS")) {   // diagnostic build: run once, print where each role's cycles go
         auto kstamp = k_swt_slide<L, NLEV, R, TH, NT, MINW, InT, LAYOUT, BF16, true>;
         if (lds > 64 * 1024)

@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libwvhash.so")
+# WVHASH_LIB: another build of the same library (A/B measurements of kernel variants, tools/build_variant.sh)
+LIB_PATH = os.environ.get("WVHASH_LIB") or os.path.join(_HERE, "_lib", "libwvhash.so")
 
 WV_DT_U8, WV_DT_F32, WV_DT_BF16 = 0, 1, 2
 WV_LAYOUT_NCHW, WV_LAYOUT_NHWC = 0, 1

@@ -18,11 +18,24 @@ from .. import _lib
 LOGGER = logging.getLogger("RETRIEVAL")
 
 
+def _stacked(features_list):
+    """S x [B, E] -> one [S, B, E] fp32 tensor.  Band features that already lie back to back in one allocation
+    (slices of a preallocated [S, B, E] buffer the backbones wrote into) are used in place, without a copy."""
+    f0 = features_list[0]
+    if f0.dtype == torch.float32 and f0.dim() == 2 and f0.is_contiguous():
+        base, step = f0.untyped_storage().data_ptr(), f0.numel() * 4
+        if all(f.dtype == torch.float32 and f.shape == f0.shape and f.is_contiguous()
+               and f.untyped_storage().data_ptr() == base and f.data_ptr() == f0.data_ptr() + i * step
+               for i, f in enumerate(features_list)):
+            return f0.as_strided((len(features_list),) + tuple(f0.shape), (f0.numel(), f0.shape[1], 1))
+    return torch.stack([f.float() for f in features_list], dim=0).contiguous()
+
+
 def band_attn_pool(features_list, q_eff, attn, norm1, norm2, mlp0, mlp2, out_proj, pool_mean=False,
                    workspace=None):
     """HIP forward of the attention-pooling core.  features_list: S x [B, E] CUDA fp32."""
     lib = _lib.require_gpu()
-    feats = torch.stack([f.float() for f in features_list], dim=0).contiguous()      # [S, B, E]
+    feats = _stacked(features_list)                                                   # [S, B, E]
     S, B, E = feats.shape
     q_eff = q_eff.detach().float().reshape(-1, E).contiguous()
     tensors = [q_eff, attn.in_proj_weight, attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias,

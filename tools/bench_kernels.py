@@ -81,7 +81,7 @@ def main():
         head = get_fusion_head({"type": "cross_attention_advanced", "output_dim": 384, "num_queries": 4}, [384] * 4)
         head.load_state_dict(synth.head_state(384, 4, "concat", 0))
         head = head.cuda().eval()
-        feats = [f.cuda() for f in synth.band_features(Q, 384, 1)]
+        feats = list(torch.stack(synth.band_features(Q, 384, 1)).cuda().unbind(0))
         with torch.no_grad():
             ms = timeit(lambda: head(feats), a.reps)
         print(f"head: {ms * 1e3:.1f} us  {Q * 14.2e6 / ms / 1e9:.1f} TFLOP/s", flush=True)
