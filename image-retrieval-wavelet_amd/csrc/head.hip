@@ -560,6 +560,91 @@ __global__ __launch_bounds__(256) void k_hash_tail(const float *__restrict__ fus
     }
 }
 
+// Same arithmetic (one fmaf chain over e per logit, in index order) for 16 samples per workgroup: the 64 weight
+// rows of the current code word are staged transposed in LDS (Wt[e][bit], pitch 65), lanes = bits, each wave
+// owns 4 samples whose features sit in LDS as float4 per e (one broadcast read).  The per-sample kernel above
+// reads every weight row from L2 with a 1.5 KB lane stride and keeps one wave in four busy.
+__global__ __launch_bounds__(256) void k_hash_tail16(const float *__restrict__ fused, int B, int E,
+                                                     const float *__restrict__ hw, const float *__restrict__ hb,
+                                                     const float *__restrict__ bn_w, const float *__restrict__ bn_b,
+                                                     const float *__restrict__ bn_mean,
+                                                     const float *__restrict__ bn_var, float eps, int nbits,
+                                                     float *__restrict__ logits_out,
+                                                     float *__restrict__ codes_out,
+                                                     uint64_t *__restrict__ packed_out)
+{
+    extern __shared__ float4 hsm4[];
+    float4 *xs4 = hsm4;                                        // [4 waves][E] : x of the wave's 4 samples at e
+    float *Wt = reinterpret_cast<float *>(hsm4 + 4 * E);       // [E][65]
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int b0 = blockIdx.x * 16;
+    {
+        float *xs = reinterpret_cast<float *>(xs4);            // element (wave w, e, sample u) at (w*E + e)*4 + u
+#pragma unroll 8
+        for (int i = tid; i < 16 * E; i += 256) {              // coalesced along e, all loads independent
+            const int sidx = i / E, e = i - sidx * E, b = b0 + sidx;
+            xs[((sidx >> 2) * E + e) * 4 + (sidx & 3)] = b < B ? fused[(size_t)b * E + e] : 0.f;
+        }
+    }
+    const int words = (nbits + 63) / 64, E4 = E / 4;
+    for (int wd = 0; wd < words; ++wd) {
+        __syncthreads();                                       // previous word's Wt fully consumed
+        constexpr int UN = 8;                                  // loads in flight per thread
+        for (int base = 0; base < 64 * E4; base += 256 * UN) {
+            f32x4 w4[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int i = base + u * 256 + tid, jj = i / E4, e4 = i - jj * E4, j = wd * 64 + jj;
+                w4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (i < 64 * E4 && j < nbits) w4[u] = *reinterpret_cast<const f32x4 *>(hw + (size_t)j * E + 4 * e4);
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int i = base + u * 256 + tid, jj = i / E4, e4 = i - jj * E4;
+                if (i < 64 * E4) {
+                    Wt[(4 * e4 + 0) * 65 + jj] = w4[u].x;
+                    Wt[(4 * e4 + 1) * 65 + jj] = w4[u].y;
+                    Wt[(4 * e4 + 2) * 65 + jj] = w4[u].z;
+                    Wt[(4 * e4 + 3) * 65 + jj] = w4[u].w;
+                }
+            }
+        }
+        __syncthreads();
+        const int j = wd * 64 + lane;
+        const bool valid = j < nbits;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const float4 *xw = xs4 + wv * E;
+#pragma unroll 16
+        for (int e = 0; e < E; ++e) {
+            const float w = Wt[e * 65 + lane];
+            const float4 x = xw[e];
+            a0 = fmaf(w, x.x, a0);
+            a1 = fmaf(w, x.y, a1);
+            a2 = fmaf(w, x.z, a2);
+            a3 = fmaf(w, x.w, a3);
+        }
+        float scale = 1.f, shift = 0.f, mean = 0.f, bias = 0.f;
+        if (valid) {
+            bias = hb ? hb[j] : 0.f;
+            if (bn_w) { mean = bn_mean[j]; scale = sqrtf(bn_var[j] + eps); shift = bn_b[j]; }
+        }
+        const float acc[4] = {a0, a1, a2, a3};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int b = b0 + 4 * wv + u;
+            float v = acc[u] + bias;
+            if (bn_w && valid) v = (v - mean) / scale * bn_w[j] + shift;
+            const bool on = valid && b < B;
+            if (on) {
+                if (logits_out) logits_out[(size_t)b * nbits + j] = v;
+                if (codes_out) codes_out[(size_t)b * nbits + j] = v > 0.f ? 1.f : (v < 0.f ? -1.f : (v == 0.f ? 0.f : v));
+            }
+            const uint64_t word = __ballot(on && v > 0.f);
+            if (packed_out && lane == 0 && b < B) packed_out[(size_t)b * words + wd] = word;
+        }
+    }
+}
+
 template <int BM, int BN, int EPI>
 static void launch_gemm_lds(const float *A, const float *W, const float *bias, const float *R, int rmod, float *C,
                             int M, int N, int K, hipStream_t st)
@@ -742,9 +827,18 @@ extern "C" int wv_hash_tail(const float *fused, int B, int E, const float *hash_
     WV_REQUIRE(!bn_w || (bn_b && bn_mean && bn_var), "hash_tail: incomplete BatchNorm parameters");
     WV_REQUIRE(E * sizeof(float) <= 48 * 1024, "hash_tail: E=%d too large", E);
     if (B == 0) return WV_OK;
-    hipLaunchKernelGGL(k_hash_tail, dim3(B), dim3(256), E * sizeof(float), (hipStream_t)stream, fused, B, E,
-                       hash_w, hash_b, bn_w, bn_b, bn_mean, bn_var, bn_eps, nbits, logits_out, codes_out,
-                       packed_out);
+    const size_t lds16 = ((size_t)4 * E * 4 + (size_t)E * 65) * sizeof(float);
+    if (lds16 <= (size_t)kMaxLdsBytes - 1024 && B >= 64 && !getenv("WV_HASH_TAIL_SIMPLE")) {
+        if (lds16 > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_hash_tail16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+        hipLaunchKernelGGL(k_hash_tail16, dim3((unsigned)ceil_div(B, 16)), dim3(256), lds16, (hipStream_t)stream, fused, B,
+                           E, hash_w, hash_b, bn_w, bn_b, bn_mean, bn_var, bn_eps, nbits, logits_out, codes_out,
+                           packed_out);
+    } else {
+        hipLaunchKernelGGL(k_hash_tail, dim3(B), dim3(256), E * sizeof(float), (hipStream_t)stream, fused, B, E,
+                           hash_w, hash_b, bn_w, bn_b, bn_mean, bn_var, bn_eps, nbits, logits_out, codes_out,
+                           packed_out);
+    }
     WV_CHECK_LAUNCH("k_hash_tail");
     return WV_OK;
 }

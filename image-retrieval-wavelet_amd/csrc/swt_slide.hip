@@ -33,6 +33,12 @@
 #ifndef WV_SWT_FASTMID
 #define WV_SWT_FASTMID 0
 #endif
+// Column pass on (row-lo, row-hi) PAIRS: the two row-filtered planes go through identical arithmetic, so the
+// consumer keeps them as 2-vectors and every multiply-add becomes one v_pk_fma_f32 -- half the instructions a
+// wave has to issue for the same (bitwise identical) result.  The LDS ring then holds the planes interleaved.
+#ifndef WV_SWT_PAIRED
+#define WV_SWT_PAIRED 1
+#endif
 
 namespace wv {
 
@@ -86,67 +92,75 @@ struct SChain {
 // inputs of every level l in registers ("tails", HALO values in all), so each step costs exactly
 // L MACs per level per new row -- no halo recompute -- and emits outputs delayed by HALO rows.
 // The arithmetic per output is identical to SChain (same taps, same order).
-template <int L, int NLEV, int N>
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ float fma_s(float s, float x, float a) { return fmaf(s, x, a); }
+__device__ __forceinline__ f32x2 fma_s(float s, f32x2 x, f32x2 a)
+{
+    const f32x2 sv = {s, s};
+    return __builtin_elementwise_fma(sv, x, a);
+}
+
+template <int L, int NLEV, int N, typename T = float>
 struct VStep {
     static constexpr int HALO = (L - 1) * ((1 << NLEV) - 1);
     // levels LEV .. NLEV-1: cur[] holds N new level-LEV inputs on entry, N new level-NLEV inputs on exit
     template <int LEV>
-    static __device__ __forceinline__ void lower(float (&cur)[N], float (&tail)[HALO], const float (&lo)[L])
+    static __device__ __forceinline__ void lower(T (&cur)[N], T (&tail)[HALO], const float (&lo)[L])
     {
         if constexpr (LEV < NLEV) {
-            constexpr int S = 1 << (LEV - 1), T = (L - 1) * S, OFF = (L - 1) * (S - 1);
-            float seq[T + N];
+            constexpr int S = 1 << (LEV - 1), TT = (L - 1) * S, OFF = (L - 1) * (S - 1);
+            T seq[TT + N];
 #pragma unroll
-            for (int i = 0; i < T; ++i) seq[i] = tail[OFF + i];
+            for (int i = 0; i < TT; ++i) seq[i] = tail[OFF + i];
 #pragma unroll
-            for (int i = 0; i < N; ++i) seq[T + i] = cur[i];
+            for (int i = 0; i < N; ++i) seq[TT + i] = cur[i];
 #pragma unroll
             for (int t = 0; t < N; ++t) {
-                float a = lo[0] * seq[t + S * (L - 1)];
+                T a = lo[0] * seq[t + S * (L - 1)];
 #pragma unroll
-                for (int m = 1; m < L; ++m) a = fmaf(lo[m], seq[t + S * (L - 1 - m)], a);
+                for (int m = 1; m < L; ++m) a = fma_s(lo[m], seq[t + S * (L - 1 - m)], a);
                 cur[t] = a;
             }
 #pragma unroll
-            for (int i = 0; i < T; ++i) tail[OFF + i] = seq[N + i];
+            for (int i = 0; i < TT; ++i) tail[OFF + i] = seq[N + i];
             lower<LEV + 1>(cur, tail, lo);
         }
     }
     // last level: seq = tail ++ cur; out(t) for t < N; tail updated
     template <typename Emit>
-    static __device__ __forceinline__ void last(const float (&cur)[N], float (&tail)[HALO], const float (&lo)[L],
+    static __device__ __forceinline__ void last(const T (&cur)[N], T (&tail)[HALO], const float (&lo)[L],
                                                 const float (&hi)[L], Emit emit)
     {
-        constexpr int S = 1 << (NLEV - 1), T = (L - 1) * S, OFF = (L - 1) * (S - 1);
-        float seq[T + N];
+        constexpr int S = 1 << (NLEV - 1), TT = (L - 1) * S, OFF = (L - 1) * (S - 1);
+        T seq[TT + N];
 #pragma unroll
-        for (int i = 0; i < T; ++i) seq[i] = tail[OFF + i];
+        for (int i = 0; i < TT; ++i) seq[i] = tail[OFF + i];
 #pragma unroll
-        for (int i = 0; i < N; ++i) seq[T + i] = cur[i];
+        for (int i = 0; i < N; ++i) seq[TT + i] = cur[i];
 #pragma unroll
         for (int t = 0; t < N; ++t) {
-            float a = lo[0] * seq[t + S * (L - 1)], d = hi[0] * seq[t + S * (L - 1)];
+            T a = lo[0] * seq[t + S * (L - 1)], d = hi[0] * seq[t + S * (L - 1)];
 #pragma unroll
             for (int m = 1; m < L; ++m) {
-                a = fmaf(lo[m], seq[t + S * (L - 1 - m)], a);
-                d = fmaf(hi[m], seq[t + S * (L - 1 - m)], d);
+                a = fma_s(lo[m], seq[t + S * (L - 1 - m)], a);
+                d = fma_s(hi[m], seq[t + S * (L - 1 - m)], d);
             }
             emit(t, a, d);
         }
 #pragma unroll
-        for (int i = 0; i < T; ++i) tail[OFF + i] = seq[N + i];
+        for (int i = 0; i < TT; ++i) tail[OFF + i] = seq[N + i];
     }
     // warm-up: only refresh the last level's tail
-    static __device__ __forceinline__ void prime_last(const float (&cur)[N], float (&tail)[HALO])
+    static __device__ __forceinline__ void prime_last(const T (&cur)[N], T (&tail)[HALO])
     {
-        constexpr int S = 1 << (NLEV - 1), T = (L - 1) * S, OFF = (L - 1) * (S - 1);
-        float seq[T + N];
+        constexpr int S = 1 << (NLEV - 1), TT = (L - 1) * S, OFF = (L - 1) * (S - 1);
+        T seq[TT + N];
 #pragma unroll
-        for (int i = 0; i < T; ++i) seq[i] = tail[OFF + i];
+        for (int i = 0; i < TT; ++i) seq[i] = tail[OFF + i];
 #pragma unroll
-        for (int i = 0; i < N; ++i) seq[T + i] = cur[i];
+        for (int i = 0; i < N; ++i) seq[TT + i] = cur[i];
 #pragma unroll
-        for (int i = 0; i < T; ++i) tail[OFF + i] = seq[N + i];
+        for (int i = 0; i < TT; ++i) tail[OFF + i] = seq[N + i];
     }
 };
 
@@ -254,6 +268,11 @@ __device__ __forceinline__ float4 s_convert4(const SRaw<InT, LAYOUT> &r, int c)
 // loads in their loop, so the compiler's vmcnt bookkeeping is unaffected.
 __device__ __forceinline__ void store_row(float *row_uniform, uint32_t byte_off, float v)
 {
+#ifdef WV_SWT_NOSTORE   // diagnostic build: arithmetic only (the store survives only for a value that never occurs)
+    if (__float_as_uint(v) == byte_off * 0x9E3779B1u + 0x7fc12345u)
+        *reinterpret_cast<float *>(reinterpret_cast<char *>(row_uniform) + byte_off) = v;
+    return;
+#endif
     asm volatile("global_store_dword %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(row_uniform) : "memory");
 }
 __device__ __forceinline__ void store_row(__hip_bfloat16 *row_uniform, uint32_t byte_off, __hip_bfloat16 v)
@@ -290,6 +309,7 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
     const int t = is_h ? threadIdx.x - NH : threadIdx.x;
 
     constexpr bool FOLD = sizeof(InT) == 1 && WV_SWT_FOLD255;
+    constexpr bool PAIRED = WV_SWT_PAIRED != 0;
     float hlo[L], hhi[L];   // taps of the last row-filter level (scaled by 1/255 when the division is folded)
 #pragma unroll
     for (int m = 0; m < L; ++m) {
@@ -336,6 +356,19 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
                     WV_STAMP(st5);
                     // LDS row layout is permuted so that consecutive lanes (= consecutive runs j) write
                     // consecutive 16-byte slots: column x = j*R + 4*q4 + e lives at q4*(4*nrun) + 4*j + e
+                    if constexpr (PAIRED) {
+                        // interleaved planes: column x = j*R + 2*q2 + e holds (lo, hi) at floats
+                        // q2*(4*nrun) + 4*j + 2*e of its row -> lanes (= runs j) write consecutive 16-byte slots
+                        float *prow = ring + (k & 1) * buf_sz + rr * (2 * P) + 4 * j;
+                        const int qstride = 4 * g.nrun;
+#pragma unroll
+                        for (int q2 = 0; q2 < R / 2; ++q2) {
+                            float4 v4;
+                            v4.x = CH::last(w, hlo, 2 * q2 + 0); v4.y = CH::last(w, hhi, 2 * q2 + 0);
+                            v4.z = CH::last(w, hlo, 2 * q2 + 1); v4.w = CH::last(w, hhi, 2 * q2 + 1);
+                            *reinterpret_cast<float4 *>(prow + q2 * qstride) = v4;
+                        }
+                    } else {
                     float *plo = ring + (k & 1) * buf_sz + rr * P + 4 * j;
                     float *phi = plo + plane_sz;
                     const int qstride = 4 * g.nrun;
@@ -348,6 +381,7 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
                         lo4.w = CH::last(w, hlo, 4 * q4 + 3); hi4.w = CH::last(w, hhi, 4 * q4 + 3);
                         *reinterpret_cast<float4 *>(plo + q4 * qstride) = lo4;
                         *reinterpret_cast<float4 *>(phi + q4 * qstride) = hi4;
+                    }
                     }
                 }
                 WV_STAMP(st2);
@@ -363,16 +397,50 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
         if (WV_SWT_VPRIO) __builtin_amdgcn_s_setprio(WV_SWT_VPRIO);   // the critical role issues first
         // this column's slot in the permuted LDS row (see pass H)
         const int tp = ((t % R) / 4) * (4 * g.nrun) + (t / R) * 4 + (t & 3);
+        const int tp2 = ((t % R) / 2) * (4 * g.nrun) + (t / R) * 4 + 2 * (t & 1);   // PAIRED layout (floats)
         for (int q = wg_in_xcd; q < nq; q += wgs_per_xcd) {
             const int m = q / g.C, pc = (xcd + g.nxcd * m) * g.C + (q - m * g.C);
             OutT *oplane = reinterpret_cast<OutT *>(out) + (size_t)pc * 4 * band;
-            float tail[2][HALO];
+            float tail[PAIRED ? 1 : 2][PAIRED ? 1 : HALO];
+            f32x2 tail2[PAIRED ? HALO : 1];
+            if constexpr (PAIRED) {
 #pragma unroll
-            for (int i = 0; i < HALO; ++i) tail[0][i] = tail[1][i] = 0.f;
+                for (int i = 0; i < HALO; ++i) tail2[i] = f32x2{0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int i = 0; i < HALO; ++i) tail[0][i] = tail[1][i] = 0.f;
+            }
             __syncthreads();       // chunk 0 produced
             for (int k = 0; k < nchunks; ++k) {
                 const int y0 = k * TH - HALO;              // first output row this chunk emits (uniform)
                 WV_STAMP(st0);
+                if constexpr (PAIRED) {
+                    if (active) {
+                        using VS = VStep<L, NLEV, TH, f32x2>;
+                        const float *col = ring + (k & 1) * buf_sz + tp2;
+                        f32x2 cur[TH];
+#pragma unroll
+                        for (int i = 0; i < TH; ++i) cur[i] = *reinterpret_cast<const f32x2 *>(col + i * (2 * P));
+                        VS::template lower<1>(cur, tail2, taps.lo);
+                        WV_STAMP(st1);
+                        if (y0 + TH <= 0) {
+                            VS::prime_last(cur, tail2);
+                        } else {
+                            // byte offsets of this lane inside the plane's 4-band block (< 2^32, host check)
+                            const uint32_t o0 = (uint32_t)t * (uint32_t)sizeof(OutT), bb = band * (uint32_t)sizeof(OutT);
+                            VS::last(cur, tail2, taps.lo, taps.hi, [&](int i, f32x2 a, f32x2 d) {
+                                const int y = y0 + i;
+                                if (y >= 0 && y < H) {
+                                    OutT *orow = oplane + (size_t)y * W;   // uniform: lives in an SGPR pair
+                                    store_row(orow, o0, (OutT)a.x);             // cA  = (row lo, col lo)
+                                    store_row(orow, o0 + bb, (OutT)d.x);        // cH  = (row lo, col hi)
+                                    store_row(orow, o0 + 2 * bb, (OutT)a.y);    // cV  = (row hi, col lo)
+                                    store_row(orow, o0 + 3 * bb, (OutT)d.y);    // cD  = (row hi, col hi)
+                                }
+                            });
+                        }
+                    }
+                } else
                 if (active) {
 #pragma unroll
                     for (int pl = 0; pl < 2; ++pl) {

@@ -131,3 +131,25 @@ def test_model_classes_end_to_end_with_stub_backbone():
                              backbones=[tiny_vit() for _ in range(4)]).cuda().eval()
     with torch.no_grad():
         assert tuple(multi(swt2d(img, "haar", 1)).shape) == (4, 32)
+
+
+@pytest.mark.parametrize("B,nbits,with_bn", [(64, 64, True), (301, 64, True), (2048, 64, True), (130, 128, False), (77, 48, True)])
+def test_hash_tail_batched_kernel_is_bit_identical_to_per_sample_kernel(B, nbits, with_bn):
+    """k_hash_tail16 (16 samples per workgroup, LDS-staged weights) runs the same fmaf chain per logit as the
+    per-sample kernel: logits, codes and packed words must be identical bit for bit."""
+    import os
+    torch.manual_seed(B + nbits)
+    fc = torch.nn.Linear(384, nbits, bias=not with_bn).cuda().eval()
+    bn = torch.nn.BatchNorm1d(nbits).cuda().eval() if with_bn else torch.nn.Identity()
+    if with_bn:
+        with torch.no_grad():
+            bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0); bn.weight.normal_(); bn.bias.normal_()
+    x = torch.randn(B, 384, device="cuda")
+    a = hash_tail(x, fc, bn, want=("logits", "codes", "packed"))
+    os.environ["WV_HASH_TAIL_SIMPLE"] = "1"
+    try:
+        b = hash_tail(x, fc, bn, want=("logits", "codes", "packed"))
+    finally:
+        del os.environ["WV_HASH_TAIL_SIMPLE"]
+    for k in ("logits", "codes", "packed"):
+        assert torch.equal(a[k], b[k]), k

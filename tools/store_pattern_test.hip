@@ -65,6 +65,56 @@ __global__ __launch_bounds__(256) void kE(float *out, float v, int planes)
         for (int i = threadIdx.x; i < 4 * H * W / 4; i += 256) o[i] = make_float4(v, v, v, v + i);
     }
 }
+// F: the sliding kernel's consumer pattern: persistent workgroups over planes, thread = column, per 16-row chunk
+// 16 rows x 4 bands of dword stores (row-major, bands interleaved).  ORDER 1: band-major inside a chunk.
+template <int ORDER, int NTH>
+__global__ __launch_bounds__(NTH) void kF(float *out, float v, int planes)
+{
+    const size_t band = (size_t)H * W;
+    const int t = threadIdx.x;
+    if (t >= W) return;
+    for (int p = blockIdx.x; p < planes; p += gridDim.x) {
+        float *o = out + (size_t)p * 4 * band + t;
+        for (int y0 = 0; y0 < H; y0 += 16) {
+            if (ORDER == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+#pragma unroll
+                    for (int bd = 0; bd < 4; ++bd) o[bd * band + (size_t)(y0 + i) * W] = v + i;
+            } else {
+#pragma unroll
+                for (int bd = 0; bd < 4; ++bd)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[bd * band + (size_t)(y0 + i) * W] = v + i;
+            }
+        }
+    }
+}
+// G: wave = band: each wave of the workgroup streams one band of the plane (16-row chunks, dword stores)
+__global__ __launch_bounds__(256) void kG(float *out, float v, int planes)
+{
+    const size_t band = (size_t)H * W;
+    const int lane = threadIdx.x & 63, bd = threadIdx.x >> 6;
+    for (int p = blockIdx.x; p < planes; p += gridDim.x) {
+        float *o = out + ((size_t)p * 4 + bd) * band;
+        for (int y0 = 0; y0 < H; y0 += 16)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+                    if (x * 64 + lane < W) o[(size_t)(y0 + i) * W + x * 64 + lane] = v + i;
+    }
+}
+// Hh: wave = band, float4 stores: 16 rows x 896 B = 3584 float4... each lane 16 B, 56 lanes cover a row
+__global__ __launch_bounds__(256) void kH(float *out, float v, int planes)
+{
+    const size_t band = (size_t)H * W;
+    const int lane = threadIdx.x & 63, bd = threadIdx.x >> 6;
+    for (int p = blockIdx.x; p < planes; p += gridDim.x) {
+        float4 *o = reinterpret_cast<float4 *>(out + ((size_t)p * 4 + bd) * band);
+        for (int i = lane; i < H * W / 4; i += 64) o[i] = make_float4(v, v, v, v + i);
+    }
+}
 int main()
 {
     const int B = 2048;
@@ -73,7 +123,7 @@ int main()
     CK(hipMalloc(&out, n * 4));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int which = 0; which < 7; ++which) {
+    for (int which = 0; which < 12; ++which) {
         float best = 1e9f;
         for (int rep = 0; rep < 5; ++rep) {
             CK(hipEventRecord(e0));
@@ -84,6 +134,11 @@ int main()
             if (which == 4) hipLaunchKernelGGL((kD<16, 512>), dim3(14, 3, B), dim3(512), 0, 0, out, 1.0f);
             if (which == 5) hipLaunchKernelGGL((kD<56, 512>), dim3(4, 3, B), dim3(512), 0, 0, out, 1.0f);
             if (which == 6) hipLaunchKernelGGL(kE, dim3(256 * 4), dim3(256), 0, 0, out, 1.0f, 3 * B);
+            if (which == 7) hipLaunchKernelGGL((kF<0, 256>), dim3(512), dim3(256), 0, 0, out, 1.0f, 3 * B);
+            if (which == 8) hipLaunchKernelGGL((kF<1, 256>), dim3(512), dim3(256), 0, 0, out, 1.0f, 3 * B);
+            if (which == 9) hipLaunchKernelGGL((kF<0, 256>), dim3(1024), dim3(256), 0, 0, out, 1.0f, 3 * B);
+            if (which == 10) hipLaunchKernelGGL(kG, dim3(1024), dim3(256), 0, 0, out, 1.0f, 3 * B);
+            if (which == 11) hipLaunchKernelGGL(kH, dim3(1024), dim3(256), 0, 0, out, 1.0f, 3 * B);
             CK(hipEventRecord(e1));
             CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
