@@ -96,6 +96,7 @@ class Pipeline:
         self.ws = Hm.TopkWorkspace()
         self.Hm = Hm
         self.db_codes_cpu = db_codes
+        self.marks, self.marks_all = None, False
 
     # -- the stages (each one C-ABI call) ---------------------------------------------------
     def stage_swt(self):
@@ -116,6 +117,13 @@ class Pipeline:
     def stage_map(self, idx):
         return self.Hm.map_at_k(idx, self.qlab, self.dblab)
 
+    def _mark(self, name, stream=None):
+        """HIP event on the stream the next / previous launch uses (only while a timing list is armed)."""
+        if self.marks is not None and (self.marks_all or name.startswith("swt")):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(stream if stream is not None else torch.cuda.current_stream())
+            self.marks.append((name, e))
+
     @torch.no_grad()
     def step(self):
         if self.swt_stream is not None:
@@ -124,13 +132,21 @@ class Pipeline:
             main = torch.cuda.current_stream()
             self.swt_stream.wait_stream(main)
             with torch.cuda.stream(self.swt_stream):
+                self._mark("swt0", self.swt_stream)
                 bands = self.stage_swt()
+                self._mark("swt1", self.swt_stream)
         else:
+            self._mark("swt0")
             bands = self.stage_swt()
+            self._mark("swt1")
         fused = self.stage_head()
+        self._mark("head1")
         packed = self.stage_tail(fused)
+        self._mark("tail1")
         idx, _ = self.stage_rank(packed)
+        self._mark("rank1")
         ap, _ = self.stage_map(idx)
+        self._mark("map1")
         if self.swt_stream is not None:
             torch.cuda.current_stream().wait_stream(self.swt_stream)
         return bands, packed, idx, ap
@@ -149,38 +165,54 @@ def time_stage(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
-def kernel_table(p, reps):
+def stage_times_in_pipeline(p, reps):
+    """Average device time of every stage inside full steps (HIP events between the stages, on the launch stream).
+    A stage timed alone, back to back, can read differently: the SWT kernel run 10x in a row averages ~8 % slower
+    than inside the step, where the head's compute-bound kernels give the write stream time to drain."""
+    p.step()
+    torch.cuda.synchronize()
+    p.marks, p.marks_all = [], True
+    for _ in range(reps):
+        p.step()
+    torch.cuda.synchronize()
+    marks, p.marks, p.marks_all = p.marks, None, False
+    per = len(marks) // reps
+    acc = {}
+    for r in range(reps):
+        m = marks[r * per:(r + 1) * per]
+        for (_, e0), (name, e1) in zip(m[:-1], m[1:]):
+            acc[name] = acc.get(name, 0.0) + e0.elapsed_time(e1)
+    return {k: v / reps for k, v in acc.items()}
+
+
+def kernel_table(p, reps, swt_ms_live):
     Q = p.Q
     with torch.no_grad():
         fused = p.stage_head()
         packed = p.stage_tail(fused)
-        idx, _ = p.Hm.hamming_topk(packed, p.db_packed_full, NBITS, TOPK, workspace=p.ws)
+        st = stage_times_in_pipeline(p, reps)
         rows = []
         # algorithmic bytes / flops per launch (SURVEY.md 8d, restated in DESIGN.md)
         swt_bytes = Q * (3 * H * W * 1 + 3 * 4 * H * W * 4)
-        rows.append(("wv_swt2d_forward[k_swt_slide db2 L3 u8->f32]", "hbm", swt_bytes,
-                     time_stage(p.stage_swt, reps)))
-        head_flops = Q * 14.2e6
-        rows.append(("wv_band_attn_pool[fp32 MFMA GEMMs + attn core + LN]", "mfma", head_flops,
-                     time_stage(p.stage_head, reps)))
-        tail_bytes = Q * (EMBED * 4 + 8) + NBITS * EMBED * 4
-        rows.append(("wv_hash_tail", "hbm", tail_bytes, time_stage(lambda: p.stage_tail(fused), reps)))
-        topk_bytes = (Q + N_DB) * NBITS // 8 + Q * TOPK * 5
-        rows.append(("wv_hamming_topk[k_hamming_topk 64b N=25000 k=5000]", "hbm", topk_bytes,
-                     time_stage(lambda: p.Hm.hamming_topk(packed, p.db_packed_full, NBITS, TOPK, workspace=p.ws), reps)))
-        dist_bytes = Q * N_DB + (Q + N_DB) * NBITS // 8
-        rows.append(("wv_hamming_dist[k_hamming_dist u8 matrix]", "hbm", dist_bytes,
-                     time_stage(lambda: p.Hm.hamming_dist(packed, p.db_packed_full), reps)))
-        map_bytes = Q * TOPK * 4 + (Q + N_DB) * 8 + Q * 8
-        rows.append(("wv_map_at_k", "hbm", map_bytes, time_stage(lambda: p.stage_map(idx), reps)))
+        rows.append(("wv_swt2d_forward[k_swt_slide db2 L3 u8->f32]", "hbm", swt_bytes, swt_ms_live,
+                     "HIP events around the launch in every timed step"))
+        how = f"HIP events between the stages of {reps} extra full steps"
+        rows.append(("wv_band_attn_pool[fp32 MFMA GEMMs + attn core + LN]", "mfma", Q * 14.2e6, st["head1"], how))
+        rows.append(("wv_hash_tail", "hbm", Q * (EMBED * 4 + 8) + NBITS * EMBED * 4, st["tail1"], how))
+        rows.append(("wv_hamming_topk[k_hamming_topk 64b N=25000 k=5000]", "hbm",
+                     (Q + N_DB) * NBITS // 8 + Q * TOPK * 5, st["rank1"], how))
+        rows.append(("wv_map_at_k", "hbm", Q * TOPK * 4 + (Q + N_DB) * 8 + Q * 8, st["map1"], how))
+        rows.append(("wv_hamming_dist[k_hamming_dist u8 matrix]", "hbm", Q * N_DB + (Q + N_DB) * NBITS // 8,
+                     time_stage(lambda: p.Hm.hamming_dist(packed, p.db_packed_full), reps),
+                     "not part of the step; timed alone, back to back"))
     out = []
-    for name, bound, work, ms in rows:
+    for name, bound, work, ms, how in rows:
         if bound == "hbm":
             ach, peak, unit = work / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
         else:
             ach, peak, unit = work / (ms * 1e-3) / 1e12, F32_MFMA_PEAK_TFLOPS, "TFLOP/s"
         out.append({"kernel": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
-                    "frac": round(ach / peak, 4), "ms": round(ms, 4), "work_per_launch": work})
+                    "frac": round(ach / peak, 4), "ms": round(ms, 4), "work_per_launch": work, "timing": how})
     return out
 
 
@@ -275,11 +307,15 @@ def main():
     for _ in range(args.warmup):
         out = p.step()
     barrier()
+    p.marks = []                       # one HIP event before and after the SWT launch of every timed step
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = p.step()
     barrier()
     elapsed = time.perf_counter() - t0
+    swt_marks, p.marks = p.marks, None
+    swt_ms = [a[1].elapsed_time(b[1]) for a, b in zip(swt_marks[0::2], swt_marks[1::2])]
+    swt_ms_live = sum(swt_ms) / max(len(swt_ms), 1)
     ap = out[3]
     cdev = device if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")
     t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -313,7 +349,7 @@ def main():
         },
     }
     if rank == 0 and world == 1:
-        kt = kernel_table(p, args.kernel_reps)
+        kt = kernel_table(p, args.kernel_reps, swt_ms_live)
         dom = max((k for k in kt if not k["kernel"].startswith("wv_hamming_dist")), key=lambda k: k["ms"])
         result["roofline"] = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"],
                               "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
