@@ -555,6 +555,40 @@ __global__ __launch_bounds__(256) void k_map_at_k(const int32_t *__restrict__ id
     }
 }
 
+// Running hit count along a ranked list: hits[q][p] = number of relevant entries among list[0..p]
+// (relevance as in k_map_at_k).  Precision@p, recall@p, R-precision and the precision/recall curves of
+// accuracy_calculator.py:131-181,235-273 are ratios of these counts.
+__global__ __launch_bounds__(256) void k_hit_prefix(const int32_t *__restrict__ idx, int k,
+                                                    const uint64_t *__restrict__ qlab,
+                                                    const uint64_t *__restrict__ dblab, int lwords,
+                                                    uint32_t *__restrict__ hits)
+{
+    __shared__ uint32_t wave_cnt[4];
+    const int qi = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int32_t *list = idx + (int64_t)qi * k;
+    uint32_t running = 0;
+    for (int p0 = 0; p0 < k; p0 += 256) {
+        const int p = p0 + tid;
+        bool rel = false;
+        if (p < k) {
+            const int32_t id = list[p];
+            if (id >= 0) {
+                uint64_t any = 0;
+                for (int w = 0; w < lwords; ++w) any |= dblab[(int64_t)id * lwords + w] & qlab[(int64_t)qi * lwords + w];
+                rel = any != 0;
+            }
+        }
+        const uint64_t mask = __ballot(rel);
+        if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        uint32_t before = running;
+        for (int w2 = 0; w2 < wv; ++w2) before += wave_cnt[w2];
+        if (p < k) hits[(int64_t)qi * k + p] = before + (uint32_t)mbcnt(mask) + (rel ? 1u : 0u);
+        running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+}
+
 static int set_lds_attr(const void *fn, size_t bytes, const char *what)
 {
     if (bytes > 64 * 1024) {
@@ -750,6 +784,17 @@ extern "C" int wv_map_at_k(const int32_t *idx, int Q, int k, const uint64_t *qla
     else
         hipLaunchKernelGGL((k_map_at_k<0>), dim3(Q), dim3(256), 0, st, idx, k, qlab, dblab, lwords, ap, nrel);
     WV_CHECK_LAUNCH("k_map_at_k");
+    return WV_OK;
+}
+
+extern "C" int wv_hit_prefix(const int32_t *idx, int Q, int k, const uint64_t *qlab, const uint64_t *dblab,
+                             int lwords, uint32_t *hits, void *stream)
+{
+    WV_REQUIRE(idx && qlab && dblab && hits, "hit_prefix: null buffer");
+    WV_REQUIRE(Q >= 0 && k >= 1 && lwords >= 1, "hit_prefix: bad shape Q=%d k=%d lwords=%d", Q, k, lwords);
+    if (Q == 0) return WV_OK;
+    hipLaunchKernelGGL(k_hit_prefix, dim3(Q), dim3(256), 0, (hipStream_t)stream, idx, k, qlab, dblab, lwords, hits);
+    WV_CHECK_LAUNCH("k_hit_prefix");
     return WV_OK;
 }
 

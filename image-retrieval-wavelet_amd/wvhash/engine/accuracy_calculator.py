@@ -9,6 +9,7 @@ arithmetic through libwvhash:
   calculate_maphashing    -> wv_hamming_topk + wv_map_at_k   (:203-231, the reported metric)
   calculate_bit_balance / calculate_worst_bit_balance -> wv_bit_counts   (:188-200)
   calculate_map           -> get_knn + wv_map_at_k  (:156-167, torchmetrics RetrievalMAP)
+  calculate_rpr / calculate_pr / calculate_pr_rc / calculate_pr_rc_hashing -> wv_hit_prefix (:131-181, :235-273)
 Ranking ties are broken by ascending reference index (see engine/get_knn.py).
 """
 import logging
@@ -38,6 +39,7 @@ class CustomCalculator(object):
         self.k = k
         self.num_top_k = k
         self.with_faiss = with_faiss
+        self.pr_rc_path, self.last_pr_rc = kwargs.pop("pr_rc_path", "pr_rc.csv"), None
         self.distance_metric = distance_metric
         # the reference pins the calculator to the CPU (main/engine/evaluate.py:76-81); here the
         # ranking stage lives on the GPU whatever `device` says
@@ -129,12 +131,20 @@ class CustomCalculator(object):
         nbits = reference.shape[1]
         return H.hamming_topk(H.pack_codes(query), H.pack_codes(reference), nbits, topk, want_dist=False)[0]
 
-    def _average_precisions(self, idx, query_labels, reference_labels):
+    @staticmethod
+    def _packed_labels(query_labels, reference_labels):
         if query_labels.ndim == 1:  # class-id labels: one-hot them onto bits
             classes = torch.unique(torch.cat([query_labels, reference_labels]))
             query_labels = (query_labels.unsqueeze(1) == classes).float()
             reference_labels = (reference_labels.unsqueeze(1) == classes).float()
-        return H.map_at_k(idx, H.pack_labels(query_labels), H.pack_labels(reference_labels))
+        return H.pack_labels(query_labels), H.pack_labels(reference_labels)
+
+    def _average_precisions(self, idx, query_labels, reference_labels):
+        return H.map_at_k(idx, *self._packed_labels(query_labels, reference_labels))
+
+    def _hits(self, idx, query_labels, reference_labels):
+        """Running hit counts along the ranked lists, int32 [Q, k] (wv_hit_prefix)."""
+        return H.hit_prefix(idx.int(), *self._packed_labels(query_labels, reference_labels))
 
     def calculate_maphashing(self, query, query_labels, reference, reference_labels, topk,
                              ref_includes_query=False, return_per_query=False, **kwargs):
@@ -162,6 +172,59 @@ class CustomCalculator(object):
         ap, _ = self._average_precisions(knn_indices.int(), query_labels, reference_labels)
         kept = ap[not_lone_query_mask]
         return kept.double().mean().item() if kept.numel() else 0.0
+
+    def calculate_rpr(self, query_labels, knn_indices, reference_labels, not_lone_query_mask, **kwargs):
+        """RetrievalRPrecision over the k-NN lists (:131-142): relevant among the first R / R, R = relevant
+        entries of the list; lists in k-NN order (ties: ascending reference index)."""
+        hits = self._hits(knn_indices, query_labels, reference_labels)[not_lone_query_mask].long()
+        if not hits.numel():
+            return 0.0
+        R = hits[:, -1]
+        top = torch.gather(hits, 1, (R - 1).clamp(min=0).unsqueeze(1)).squeeze(1)
+        return torch.where(R > 0, top.double() / R.clamp(min=1).double(), torch.zeros_like(R, dtype=torch.float64)) \
+            .mean().item()
+
+    def calculate_pr(self, query_labels, knn_indices, reference_labels, not_lone_query_mask, **kwargs):
+        """RetrievalPrecision(top_k=1) (:144-154)."""
+        first = self._hits(knn_indices[:, :1], query_labels, reference_labels)[not_lone_query_mask]
+        return first.double().mean().item() if first.numel() else 0.0
+
+    def _curves(self, hits):
+        """precision@j, recall@j (j = 1..k) averaged over the rows of `hits`; rows without a hit count zero."""
+        h = hits.double()
+        tot = h[:, -1:]
+        j = torch.arange(1, h.shape[1] + 1, dtype=torch.float64, device=h.device)
+        has = tot > 0
+        prec = torch.where(has, h / j, torch.zeros_like(h)).mean(0)
+        rec = torch.where(has, h / tot.clamp(min=1), torch.zeros_like(h)).mean(0)
+        return prec, rec
+
+    def _write_pr_rc(self, prec, rec):
+        self.last_pr_rc = (prec, rec)
+        if self.pr_rc_path:                           # the reference writes ./pr_rc.csv as a side effect
+            import pandas as pd
+            pd.DataFrame({"pr": prec.cpu().numpy(), "rc": rec.cpu().numpy()}).to_csv(self.pr_rc_path, index=False)
+
+    def calculate_pr_rc(self, query_labels, knn_indices, reference_labels, not_lone_query_mask, **kwargs):
+        """RetrievalPrecisionRecallCurve over the k-NN lists (:169-181): writes the curve, returns 0."""
+        hits = self._hits(knn_indices, query_labels, reference_labels)[not_lone_query_mask]
+        if hits.numel():
+            self._write_pr_rc(*self._curves(hits))
+        return 0
+
+    def calculate_pr_rc_hashing(self, query, query_labels, reference, reference_labels, not_lone_query_mask=None,
+                                **kwargs):
+        """Full-gallery precision / recall curves along the Hamming ranking (:235-273), averaged over the
+        queries that are not lone and have a relevant item; writes the curve, returns 0."""
+        query, reference = _to_gpu(query), _to_gpu(reference)
+        query_labels, reference_labels = _to_gpu(query_labels), _to_gpu(reference_labels)
+        hits = self._hits(self._ranked_lists(query, reference, reference.shape[0]), query_labels, reference_labels)
+        ok = hits[:, -1] > 0
+        if not_lone_query_mask is not None:
+            ok &= not_lone_query_mask
+        if bool(ok.any()):
+            self._write_pr_rc(*self._curves(hits[ok]))
+        return 0
 
     def _knn_relevance(self, query_labels, knn_labels, k):
         return self.label_comparison_fn(query_labels[:, None], knn_labels[:, :k]) if query_labels.ndim > 1 \
@@ -198,6 +261,9 @@ class CustomCalculator(object):
         }
 
         knn_indices = None
+        if "pr_rc_hashing" in self.get_curr_metrics():
+            kwargs["not_lone_query_mask"] = (self._match_counts(query_labels, reference_labels)
+                                             - int(embeddings_come_from_same_source)) > 0
         if any(x in self.requires_knn() for x in self.get_curr_metrics()):
             match_counts = self._match_counts(query_labels, reference_labels)
             self_count = int(embeddings_come_from_same_source)

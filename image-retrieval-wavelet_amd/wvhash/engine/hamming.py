@@ -215,3 +215,19 @@ def map_at_k(idx, qlab_packed, dblab_packed):
                                  lw, _lib.ptr(ap), _lib.ptr(nrel), _lib.stream_ptr())
             _lib.check(rc, "wv_map_at_k")
     return ap, nrel
+
+
+def hit_prefix(idx, qlab_packed, dblab_packed):
+    """hits[q, p] = number of relevant entries among idx[q, :p+1] (uint32 counts as int32 tensor [Q, k])."""
+    lib = _lib.require_gpu()
+    Q, k = idx.shape
+    lw = qlab_packed.shape[1]
+    if dblab_packed.shape[1] != lw:
+        raise ValueError("hit_prefix: label widths differ")
+    hits = torch.empty((Q, k), dtype=torch.int32, device=idx.device)
+    if Q:
+        with torch.cuda.device(idx.device):
+            rc = lib.wv_hit_prefix(_lib.ptr(idx.contiguous()), Q, k, _lib.ptr(qlab_packed), _lib.ptr(dblab_packed),
+                                   lw, _lib.ptr(hits), _lib.stream_ptr())
+            _lib.check(rc, "wv_hit_prefix")
+    return hits

@@ -165,6 +165,13 @@ int wv_rank_from_dist(const uint8_t *dist_matrix, int64_t ld_dist, int Q, int64_
 int wv_map_at_k(const int32_t *idx, int Q, int k, const uint64_t *qlab, const uint64_t *dblab,
                 int lwords, float *ap, int32_t *nrel, void *stream);
 
+/* Running hit counts along each ranked list: hits[q][p] = relevant entries among idx[q][0..p] (uint32 [Q][k]).
+ * The ratios of these counts are the secondary retrieval diagnostics of accuracy_calculator.py:131-181
+ * (RetrievalRPrecision, RetrievalPrecision(top_k=1), RetrievalPrecisionRecallCurve) and the full-gallery
+ * precision/recall curves of calculate_pr_rc_hashing (:235-273).  Same relevance rule as wv_map_at_k. */
+int wv_hit_prefix(const int32_t *idx, int Q, int k, const uint64_t *qlab, const uint64_t *dblab,
+                  int lwords, uint32_t *hits, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Real-valued k-NN (non-binary embeddings).  Replaces get_knn_torch (get_knn.py:60-71):
  *   metric 0: scores = q @ r.T,           top-k largest  (hamming / cosine branch)

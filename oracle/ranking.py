@@ -177,6 +177,66 @@ def retrieval_map(knn_scores, relevances, not_lone_query_mask=None):
     return float(sum(aps) / max(len(aps), 1))
 
 
+def retrieval_rprecision(relevances, not_lone_query_mask=None):
+    """torchmetrics RetrievalRPrecision as called at accuracy_calculator.py:131-142: per query R = number of
+    relevant items in its list, value = relevant among the first R / R (0 when R = 0), mean over kept queries.
+    Lists are taken in k-NN order (canonical tie-break; the reference perturbs tied scores by 1e-8 * position)."""
+    Q = relevances.shape[0]
+    keep = torch.ones(Q, dtype=torch.bool) if not_lone_query_mask is None else not_lone_query_mask
+    vals = []
+    for i in range(Q):
+        if not bool(keep[i]):
+            continue
+        t = relevances[i].bool()
+        R = int(t.sum())
+        vals.append(float(t[:R].sum()) / R if R else 0.0)
+    return float(sum(vals) / max(len(vals), 1))
+
+
+def retrieval_precision_at_1(relevances, not_lone_query_mask=None):
+    """RetrievalPrecision(top_k=1) (accuracy_calculator.py:144-154)."""
+    keep = torch.ones(relevances.shape[0], dtype=torch.bool) if not_lone_query_mask is None else not_lone_query_mask
+    r = relevances[keep][:, 0].float()
+    return float(r.mean()) if r.numel() else 0.0
+
+
+def retrieval_pr_curve(relevances, not_lone_query_mask=None):
+    """RetrievalPrecisionRecallCurve (accuracy_calculator.py:169-181): precision@j and recall@j for
+    j = 1..k averaged over the kept queries, queries without a positive contributing zeros."""
+    keep = torch.ones(relevances.shape[0], dtype=torch.bool) if not_lone_query_mask is None else not_lone_query_mask
+    t = relevances[keep].double()
+    k = t.shape[1]
+    csum = t.cumsum(1)
+    j = torch.arange(1, k + 1, dtype=torch.float64)
+    tot = csum[:, -1:]
+    prec = csum / j
+    rec = torch.where(tot > 0, csum / tot.clamp(min=1), torch.zeros_like(csum))
+    prec = torch.where(tot > 0, prec, torch.zeros_like(prec))
+    return prec.mean(0), rec.mean(0)
+
+
+def pr_rc_hashing(query, query_labels, reference, reference_labels, not_lone_query_mask, stable=True):
+    """calculate_pr_rc_hashing (accuracy_calculator.py:235-273): per query the full-gallery precision and
+    recall curves along the Hamming ranking; mean over the queries that are not lone and reach recall 1.
+    Returns (precision [N], recall [N]) or None when no query qualifies."""
+    nq, ng = query.shape[0], reference.shape[0]
+    all_prec = torch.zeros((nq, ng))
+    all_rec = torch.zeros((nq, ng))
+    for i in range(nq):
+        gnd = label_comparison_fn(query_labels[i:i + 1], reference_labels).float().squeeze()
+        hamm = calc_hamming_dist(query[i:i + 1], reference).squeeze()
+        gnd = gnd[torch.argsort(hamm, stable=stable)]
+        tot = gnd.sum()
+        if tot > 0:
+            c = torch.cumsum(gnd, 0)
+            all_prec[i] = c / torch.arange(1, ng + 1).float()
+            all_rec[i] = c / tot
+    ok = (all_rec[:, -1] == 1.0) & not_lone_query_mask
+    if not bool(ok.any()):
+        return None
+    return all_prec[ok].mean(0), all_rec[ok].mean(0)
+
+
 # ----------------------------------------------------------------------------- synthetic inputs
 def make_codes(n_query, n_db, nbits, seed=0):
     """Random +-1 codes exactly as studies/measure_random_baseline.py:84,105-106 builds them

@@ -222,10 +222,10 @@ def test_get_accuracy_driver_metrics():
     ql, rl = synth.multi_hot_labels(Q, 38, 0.10, 1), synth.multi_hot_labels(N, 38, 0.10, 2)
     q, r = synth.structured_codes(ql, nbits, 3, 4), synth.structured_codes(rl, nbits, 3, 5)
     from wvhash.engine import get_accuracy_calculator
-    calc = get_accuracy_calculator(k=k, distance_metric="hamming", with_faiss=False,
-                                   exclude=["mean_reciprocal_rank", "precision_at_1", "r_precision", "rpr"])
+    calc = get_accuracy_calculator(k=k, distance_metric="hamming", with_faiss=False, pr_rc_path=None,
+                                   exclude=["mean_reciprocal_rank", "precision_at_1", "r_precision"])
     acc = calc.get_accuracy(q, ql, r, rl, False)
-    assert set(acc) == {"maphashing", "map", "bit_balance", "worst_bit_balance"}
+    assert set(acc) == {"maphashing", "map", "bit_balance", "worst_bit_balance", "rpr", "pr", "pr_rc"}
     m_st = ranking.calculate_maphashing(q, ql, r, rl, k, stable=True)
     assert abs(acc["maphashing"] - m_st) < AP_TOL
     # map_level0 = RetrievalMAP over the k-NN lists = same lists here -> same APs, mean over non-lone queries
@@ -233,8 +233,34 @@ def test_get_accuracy_driver_metrics():
     rel = torch.stack([ranking.label_comparison_fn(ql[i:i + 1], rl[si[i]])[0] for i in range(Q)])
     assert abs(acc["map"] - ranking.retrieval_map(sd, rel)) < AP_TOL
     assert abs(acc["bit_balance"] - ranking.calculate_bit_balance(r)) < 1e-6
+    # secondary diagnostics (torchmetrics RetrievalRPrecision / RetrievalPrecision(top_k=1) / PR curve)
+    assert abs(acc["rpr"] - ranking.retrieval_rprecision(rel)) < 1e-9
+    assert abs(acc["pr"] - ranking.retrieval_precision_at_1(rel)) < 1e-9
+    assert acc["pr_rc"] == 0
+    pr_ref, rc_ref = ranking.retrieval_pr_curve(rel)
+    pr, rc = calc.last_pr_rc
+    assert torch.allclose(pr.cpu(), pr_ref, atol=1e-12) and torch.allclose(rc.cpu(), rc_ref, atol=1e-12)
     idx, acc2 = calc.get_accuracy(q, ql, r, rl, False, return_indices=True)
     assert torch.equal(idx.cpu(), si) and acc2 == acc
+
+
+def test_pr_rc_hashing_full_gallery_curves(tmp_path):
+    Q, N, nbits = 24, 1500, 32
+    ql, rl = synth.multi_hot_labels(Q, 20, 0.07, 5), synth.multi_hot_labels(N, 20, 0.07, 6)
+    ql[3] = 0                                    # a query without any relevant item: excluded from the mean
+    q, r = synth.structured_codes(ql, nbits, 3, 7), synth.structured_codes(rl, nbits, 3, 8)
+    from wvhash.engine import CustomCalculator
+    out = tmp_path / "pr_rc.csv"
+    calc = CustomCalculator(include=("pr_rc_hashing",), k=N, distance_metric="hamming", pr_rc_path=str(out))
+    acc = calc.get_accuracy(q, ql, r, rl, False)
+    assert acc == {"pr_rc_hashing": 0}
+    lone = (ranking.label_comparison_fn(ql, rl).sum(1) > 0)
+    pr_ref, rc_ref = ranking.pr_rc_hashing(q, ql, r, rl, lone, stable=True)
+    pr, rc = calc.last_pr_rc
+    assert torch.allclose(pr.cpu().float(), pr_ref, atol=1e-6) and torch.allclose(rc.cpu().float(), rc_ref, atol=1e-6)
+    import pandas as pd
+    df = pd.read_csv(out)
+    assert list(df.columns) == ["pr", "rc"] and len(df) == N and abs(df["rc"].iloc[-1] - 1.0) < 1e-12
 
 
 def test_coco_shape_128bit_u32_path_k5000_and_all():
