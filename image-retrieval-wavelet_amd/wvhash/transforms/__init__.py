@@ -1,6 +1,7 @@
 from .custom_transforms import SWTTransform, DWTTransform, RawStackTransform, BaseWaveletTransform
 from .functional import swt2d, dwt2d, rawstack
 from .wavelets import get_filters, wavelist
+from .pil_ops import Resize, CenterCrop, Compose, build_transform
 
 __all__ = ["SWTTransform", "DWTTransform", "RawStackTransform", "BaseWaveletTransform", "swt2d",
-           "dwt2d", "rawstack", "get_filters", "wavelist"]
+           "dwt2d", "rawstack", "get_filters", "wavelist", "Resize", "CenterCrop", "Compose", "build_transform"]

@@ -80,3 +80,32 @@ def test_evaluate_multi_k_embeds_once(setup):
         ref, _ = oracle_metrics(net, dts, k)
         assert abs(res[k]["test"]["maphashing_level0"] - ref) < 1e-6
         assert "map_level0" not in res[k]["test"]
+
+
+def test_evaluate_on_split_files_through_the_yaml_pipeline(setup, tmp_path):
+    """database.txt / test.txt + image files -> Resize/CenterCrop/SWTTransform (deferred) -> evaluate():
+    the data formats either side of the hot path (flikr_coco.py:7-63, basic_swt.yaml, getter.py:25-35)."""
+    from wvhash.datasets import MIRFlickrHashing
+    from wvhash.transforms import build_transform
+    net, _ = setup
+    rng = np.random.default_rng(11)
+    (tmp_path / "images").mkdir()
+    for fname, n, seed in (("test.txt", 10, 3), ("database.txt", 48, 4)):
+        labels = synth.multi_hot_labels(n, 38, 0.10, seed)
+        imgs = synth.natural_images(n, 260, 300 + 10 * seed, seed=seed)
+        with open(tmp_path / fname, "w") as f:
+            for i in range(n):
+                name = f"{fname[:2]}{i}.png"
+                Image.fromarray(imgs[i]).save(tmp_path / "images" / name)
+                f.write(name + " " + " ".join(str(int(v)) for v in labels[i]) + "\n")
+    tf = build_transform({"Resize": {"size": 256}, "CenterCrop": {"size": 224},
+                          "SWTTransform": {"level": 1, "wavelet": "haar"}}, defer=True)
+    dts = {"test": MIRFlickrHashing(str(tmp_path), "test", tf), "gallery": MIRFlickrHashing(str(tmp_path), "gallery", tf)}
+    m = evaluate(net, test_dataset=dts, epoch=0, batch_size=16, num_workers=0, k=30, distance_metric="hamming",
+                 pr_rc_path=None, exclude=["mean_reciprocal_rank", "precision_at_1", "r_precision"])
+    with torch.no_grad():
+        enc = lambda d: net(torch.stack([d[i]["image"] for i in range(len(d))]).cuda()).cpu()
+        q, r = enc(dts["test"]), enc(dts["gallery"])
+    ref = ranking.calculate_maphashing(q, dts["test"].label_matrix, r, dts["gallery"].label_matrix, 30, stable=True)
+    assert abs(m["test"]["maphashing_level0"] - ref) < 1e-6
+    assert {"rpr_level0", "pr_level0", "map_level0"} <= set(m["test"])
