@@ -108,7 +108,7 @@ class CrossAttentionBottleneckHeadAdvanced(nn.Module):
     def _ortho_after_attention(self, attn_weights, mask_ll, device):
         if self.training and self.ortho_weight > 0:
             return self.compute_ortho_loss()
-        return torch.tensor(0.0, device=device)
+        return torch.zeros((), device=device)
 
     def _readout(self, x, batch_size):
         return x.mean(dim=1) if self._pool == "mean" else x.view(batch_size, -1)
@@ -129,7 +129,9 @@ class CrossAttentionBottleneckHeadAdvanced(nn.Module):
         kv_list = [proj(f) for proj, f in zip(self.projections, features_list)]
 
         if self._hip_ok(kv_list):
-            self.last_ortho_loss = torch.tensor(0.0, device=device)
+            # torch.zeros launches a fill on the stream; torch.tensor(0.0, device=...) is a blocking host-to-device
+            # copy that drains everything queued before it (here: the whole SWT kernel of the step)
+            self.last_ortho_loss = torch.zeros((), device=device)
             with torch.no_grad():
                 out = band_attn_pool(kv_list, self.effective_queries(), self.attn, self.norm1, self.norm2,
                                      self.mlp[0], self.mlp[2], self.out_proj, self._pool == "mean", self._ws)
