@@ -91,6 +91,7 @@ class CrossAttentionBottleneckHeadAdvanced(nn.Module):
         self.out_proj = nn.Linear(in_dim, embed_dim)
         self.last_ortho_loss = 0.0
         self._ws = None
+        self._zero_loss = None
 
     # -- pieces shared by the four variants ------------------------------------------------
     def compute_ortho_loss(self):
@@ -131,7 +132,9 @@ class CrossAttentionBottleneckHeadAdvanced(nn.Module):
         if self._hip_ok(kv_list):
             # torch.zeros launches a fill on the stream; torch.tensor(0.0, device=...) is a blocking host-to-device
             # copy that drains everything queued before it (here: the whole SWT kernel of the step)
-            self.last_ortho_loss = torch.zeros((), device=device)
+            if self._zero_loss is None or self._zero_loss.device != device:
+                self._zero_loss = torch.zeros((), device=device)
+            self.last_ortho_loss = self._zero_loss
             with torch.no_grad():
                 out = band_attn_pool(kv_list, self.effective_queries(), self.attn, self.norm1, self.norm2,
                                      self.mlp[0], self.mlp[2], self.out_proj, self._pool == "mean", self._ws)
