@@ -589,6 +589,70 @@ __global__ __launch_bounds__(256) void k_hit_prefix(const int32_t *__restrict__ 
     }
 }
 
+// Compact form of the same merge for the sharded search: a shard does not send its distance rows (1 byte per
+// entry) but its cumulative distance histogram (cum[b] = rows of the shard with distance < b, nbins + 1 words per
+// query -- the k_hamming_topk by-product), and its list as 16-bit LOCAL row numbers (shards of <= 65536 rows).
+// A sorted list is fully described by its histogram: run boundaries are min(cum[b], kin) directly, an entry's
+// distance is the bin its position falls in (binary search over the boundaries in LDS), its global index is
+// local + g * shard_rows.  Same output as k_merge_sorted on the expanded inputs.
+__global__ __launch_bounds__(256) void k_merge_cum(const uint16_t *__restrict__ idx_local,
+                                                   const uint32_t *__restrict__ cum, int G, int Q, int kin,
+                                                   int64_t shard_rows, int32_t *__restrict__ idx_out,
+                                                   uint8_t *__restrict__ dist_out, int k, int nbins)
+{
+    extern __shared__ uint4 lds4[];
+    int32_t *start = reinterpret_cast<int32_t *>(lds4);           // [G][nbins + 1]: first position with dist >= b
+    int32_t *delta = start + G * (nbins + 1);                     // [G][nbins]
+    uint32_t *base = reinterpret_cast<uint32_t *>(delta + G * nbins);   // [nbins + 1]
+    const int qi = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    for (int u = tid; u < G * (nbins + 1); u += 256) {
+        const int g = u / (nbins + 1), b = u - g * (nbins + 1);
+        start[u] = (int32_t)min(cum[((int64_t)g * Q + qi) * (nbins + 1) + b], (uint32_t)kin);
+    }
+    __syncthreads();
+    if (wv == 0) {   // totals per bin and their exclusive scan (up to 3 bins per lane)
+        uint32_t t[3] = {0, 0, 0};
+        const int b0 = 3 * lane;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (b0 + j < nbins)
+                for (int g = 0; g < G; ++g) t[j] += (uint32_t)(start[g * (nbins + 1) + b0 + j + 1] - start[g * (nbins + 1) + b0 + j]);
+        const uint32_t incl = wave_incl_scan_u32(t[0] + t[1] + t[2]);
+        const uint32_t excl = incl - (t[0] + t[1] + t[2]);
+        if (b0 < nbins) base[b0] = excl;
+        if (b0 + 1 < nbins) base[b0 + 1] = excl + t[0];
+        if (b0 + 2 < nbins) base[b0 + 2] = excl + t[0] + t[1];
+    }
+    __syncthreads();
+    for (int b = tid; b < nbins; b += 256) {
+        uint32_t run = base[b];
+        for (int g = 0; g < G; ++g) {
+            const int s0 = start[g * (nbins + 1) + b], s1 = start[g * (nbins + 1) + b + 1];
+            delta[g * nbins + b] = (int32_t)run - s0;
+            run += (uint32_t)(s1 - s0);
+        }
+    }
+    __syncthreads();
+    for (int g = 0; g < G; ++g) {
+        const uint16_t *irow = idx_local + ((int64_t)g * Q + qi) * kin;
+        const int32_t *st = start + g * (nbins + 1);
+        const int len = st[nbins];                                // entries this shard really sent
+        for (int p = tid; p < len; p += 256) {
+            int lo = 0, hi = nbins;                               // invariant: st[lo] <= p < st[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (st[mid] <= p) lo = mid;
+                else hi = mid;
+            }
+            const int pos = p + delta[g * nbins + lo];
+            if (pos < k) {
+                idx_out[(int64_t)qi * k + pos] = (int32_t)((int64_t)irow[p] + g * shard_rows);
+                if (dist_out) dist_out[(int64_t)qi * k + pos] = (uint8_t)lo;
+            }
+        }
+    }
+}
+
 static int set_lds_attr(const void *fn, size_t bytes, const char *what)
 {
     if (bytes > 64 * 1024) {
@@ -742,6 +806,25 @@ extern "C" int wv_topk_merge(const int32_t *idx_in, const uint8_t *dist_in, int 
     hipLaunchKernelGGL(k_merge_sorted, dim3(Q), dim3(256), lds, (hipStream_t)stream, idx_in, dist_in, G, Q, kin,
                        idx_out, dist_out, k, nbins);
     WV_CHECK_LAUNCH("k_merge_sorted");
+    return WV_OK;
+}
+
+extern "C" int wv_topk_merge_cum(const uint16_t *idx_local, const uint32_t *cum, int G, int Q, int kin,
+                                 int64_t shard_rows, int32_t *idx_out, uint8_t *dist_out, int k, int nbits, void *stream)
+{
+    WV_REQUIRE(idx_local && cum && idx_out, "topk_merge_cum: null buffer");
+    WV_REQUIRE(G >= 1 && Q >= 0 && kin >= 1 && k >= 1, "topk_merge_cum: bad shape G=%d Q=%d kin=%d k=%d", G, Q, kin, k);
+    WV_REQUIRE(nbits >= 1 && nbits <= 128, "topk_merge_cum: nbits=%d (supported: 1..128)", nbits);
+    WV_REQUIRE(shard_rows >= 1 && shard_rows <= 65536, "topk_merge_cum: %lld rows per shard do not fit 16-bit local indices",
+               (long long)shard_rows);
+    WV_REQUIRE((int64_t)G * shard_rows <= 0x7fffffffLL, "topk_merge_cum: indices exceed int32");
+    if (Q == 0) return WV_OK;
+    const int nbins = nbits + 1;
+    const size_t lds = ((size_t)G * (nbins + 1) + (size_t)G * nbins + nbins + 1 + 4) * 4;
+    WV_REQUIRE(lds <= 60 * 1024, "topk_merge_cum: too many shards (G=%d)", G);
+    hipLaunchKernelGGL(k_merge_cum, dim3(Q), dim3(256), lds, (hipStream_t)stream, idx_local, cum, G, Q, kin, shard_rows,
+                       idx_out, dist_out, k, nbins);
+    WV_CHECK_LAUNCH("k_merge_cum");
     return WV_OK;
 }
 

@@ -66,6 +66,7 @@ SIGNATURES = {
     "wv_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
     "wv_rank_from_dist": (_i, [_vp, _i64, _i, _i64, _i, _vp, _vp, _i, _vp]),
     "wv_map_at_k": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "wv_topk_merge_cum": (_i, [_vp, _vp, _i, _i, _i, _i64, _vp, _vp, _i, _i, _vp]),
     "wv_hit_prefix": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "wv_knn_float_workspace_bytes": (_sz, [_i, _i64, _i, _i]),
     "wv_knn_float": (_i, [_vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),

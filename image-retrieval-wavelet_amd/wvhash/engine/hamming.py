@@ -186,6 +186,23 @@ def topk_merge(idx_in, dist_in, k, nbits):
     return idx, dist
 
 
+def topk_merge_cum(idx_local, cum, shard_rows, k, nbits):
+    """Compact merge: idx_local int16 storage of uint16 LOCAL row numbers [G,Q,kin], cum int32 [G,Q,nbits+2]
+    (per-shard cumulative distance histograms) -> global (idx int32 [Q,k], dist uint8 [Q,k])."""
+    lib = _lib.require_gpu()
+    G, Q, kin = idx_local.shape
+    if idx_local.dtype != torch.int16 or cum.dtype != torch.int32 or tuple(cum.shape) != (G, Q, nbits + 2):
+        raise ValueError("topk_merge_cum: expected int16 [G,Q,kin] local indices and int32 [G,Q,nbits+2] histograms")
+    idx_local, cum = idx_local.contiguous(), cum.contiguous()
+    idx = torch.empty((Q, k), dtype=torch.int32, device=idx_local.device)
+    dist = torch.empty((Q, k), dtype=torch.uint8, device=idx_local.device)
+    with torch.cuda.device(idx_local.device):
+        rc = lib.wv_topk_merge_cum(_lib.ptr(idx_local), _lib.ptr(cum), G, Q, kin, shard_rows, _lib.ptr(idx),
+                                   _lib.ptr(dist), k, nbits, _lib.stream_ptr())
+        _lib.check(rc, "wv_topk_merge_cum")
+    return idx, dist
+
+
 def rank_from_dist(dist_matrix, nbits, k):
     lib = _lib.require_gpu()
     Q, N = dist_matrix.shape

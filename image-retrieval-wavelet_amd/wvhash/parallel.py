@@ -6,10 +6,11 @@ per shard, per-shard top-k merged on the HOST.  Here the shards stay resident in
 and the only exchange steps are
   1. all_gather of the packed query codes (Q * nbits/8 bytes per rank -- tiny), so every rank can rank
      every query against its shard;
-  2. all_to_all of the per-shard top-k lists (int32 index + uint8 distance): rank r receives, from
-     every shard, the lists of ITS queries only (an all_gather would move world_size times more);
-  3. a local G-way merge on the GPU (wv_topk_merge), exact and identical for every world size because
-     lists are ordered by (distance, global index) and shards are contiguous row ranges in rank order.
+  2. all_to_all of the per-shard list prefixes: rank r receives, from every shard, the lists of ITS queries only
+     (an all_gather would move world_size times more) -- as 16-bit local row numbers plus the shard's cumulative
+     distance histogram per query (compact form), or int32 index + uint8 distance when a shard has > 65536 rows;
+  3. a local G-way merge on the GPU (wv_topk_merge_cum / wv_topk_merge), exact and identical for every world
+     size because lists are ordered by (distance, global index) and shards are contiguous row ranges in rank order.
 xGMI is point-to-point: with 8 GPUs fully connected both collectives are one direct exchange per peer.
 """
 import torch
@@ -91,8 +92,9 @@ def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, works
     i = d = cum = None
     if k_local > 0:
         if trim:
+            # the compact exchange below ships histograms, not distance rows: do not even write them
             i, d, cum = H.hamming_topk(q_all, db_shard, nbits, k_local, idx_offset=lo, workspace=workspace,
-                                       want_cum=True)
+                                       want_dist=per > 65536, want_cum=True)
         else:
             i, d = H.hamming_topk(q_all, db_shard, nbits, k_local, idx_offset=lo, workspace=workspace)
     send = kin
@@ -106,6 +108,21 @@ def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, works
         need = torch.gather(cum, 1, (T + 1).unsqueeze(1).long()).max().reshape(1)   # local rows with distance <= T
         _all_reduce(need, dist.ReduceOp.MAX, group)
         send = max(1, min(kin, int(need.item())))       # the one host read of the exchange
+    if trim and per <= 65536:
+        # compact exchange: 16-bit LOCAL row numbers (2 bytes/entry) and, instead of a distance row, the shard's
+        # cumulative histogram of each query (a sorted list is fully described by it): 2 bytes per entry + 4*(nbits+2)
+        # bytes per (query, shard) on the wire instead of 5 bytes per entry.  int16 storage, shipped as bytes (RCCL has
+        # no 16-bit integer type).
+        loc_s = torch.zeros((world * Ql, send), dtype=torch.int16, device=dev)
+        if k_local > 0:
+            w = min(send, k_local)
+            loc_s[:, :w] = (i[:, :w] - lo).to(torch.int16)       # wraps for rows >= 32768; the kernel reads uint16
+        loc_r = torch.empty_like(loc_s)
+        _all_to_all(loc_r.view(torch.uint8), loc_s.view(torch.uint8), group)
+        cum_r = torch.empty_like(cum)
+        _all_to_all(cum_r, cum.contiguous(), group)
+        # received layout: [shard g][my Ql queries][...]
+        return H.topk_merge_cum(loc_r.view(world, Ql, send), cum_r.view(world, Ql, nbits + 2), per, k, nbits)
     idx_s = torch.full((world * Ql, send), -1, dtype=torch.int32, device=dev)
     dist_s = torch.full((world * Ql, send), pad_value(nbits), dtype=torch.uint8, device=dev)
     if k_local > 0:

@@ -149,6 +149,15 @@ int wv_hamming_topk_ex(const uint64_t *q, const uint64_t *db, const void *prepar
 int wv_topk_merge(const int32_t *idx_in, const uint8_t *dist_in, int G, int Q, int kin,
                   int32_t *idx_out, uint8_t *dist_out, int k, int nbits, void *stream);
 
+/* Compact merge for the sharded search: every shard sends, per query, its cumulative distance histogram
+ * (cum, uint32 [G][Q][nbits + 2], the `cum` output of wv_hamming_topk_ex: rows with distance < b) instead of a
+ * distance row, and its list as 16-bit LOCAL row numbers (idx_local uint16 [G][Q][kin], shard_rows <= 65536;
+ * shard g holds global rows [g * shard_rows, ...)).  A sorted list is fully described by its histogram.
+ * Output as wv_topk_merge.  Replaces the host merge of faiss' sharded index (get_knn.py:41-44) with 2.2x fewer
+ * exchanged bytes than int32 indices + uint8 distances. */
+int wv_topk_merge_cum(const uint16_t *idx_local, const uint32_t *cum, int G, int Q, int kin, int64_t shard_rows,
+                      int32_t *idx_out, uint8_t *dist_out, int k, int nbits, void *stream);
+
 /* Ranking from a stored distance matrix row (same order as wv_hamming_topk). */
 int wv_rank_from_dist(const uint8_t *dist_matrix, int64_t ld_dist, int Q, int64_t N, int nbits,
                       int32_t *idx, uint8_t *dist, int k, void *stream);

@@ -154,6 +154,42 @@ def test_topk_merge_of_row_shards_equals_unsharded():
         assert torch.equal(mi, full_idx) and torch.equal(md, full_d)
 
 
+@pytest.mark.parametrize("N,nbits,k,G,send", [(11000, 64, 3000, 8, None), (11000, 64, 3000, 7, 900), (70000, 128, 5000, 2, 4000),
+                                              (999, 16, 999, 3, None), (40, 32, 7, 5, None)])
+def test_compact_merge_from_histograms_equals_unsharded(N, nbits, k, G, send):
+    """wv_topk_merge_cum: shards ship 16-bit local row numbers + their cumulative distance histograms (what the
+    sharded search exchanges); the merged lists equal the unsharded ranking.  `send` < needed is never used by the
+    search (it sizes the prefix from the global threshold), so a trimmed prefix must still give the exact top k
+    whenever it covers every shard's entries below the global threshold -- here: send = None means full lists."""
+    Q = 19
+    q, r = synth.random_codes(Q, N, nbits, seed=7)
+    qp, rp = H.pack_codes(q.cuda()), H.pack_codes(r.cuda())
+    full_idx, full_d = H.hamming_topk(qp, rp, nbits, k)
+    per = (N + G - 1) // G
+    kin = min(k, per)
+    lists, cums = [], []
+    for g in range(G):
+        lo, hi = min(N, g * per), min(N, (g + 1) * per)
+        kk = min(kin, hi - lo)
+        loc = torch.zeros((Q, kin), dtype=torch.int16, device="cuda")
+        cum = torch.zeros((Q, nbits + 2), dtype=torch.int32, device="cuda")
+        if kk > 0:
+            i, _, cum = H.hamming_topk(qp, rp[lo:hi].contiguous(), nbits, kk, idx_offset=lo, want_dist=False, want_cum=True)
+            loc[:, :kk] = (i - lo).to(torch.int16)
+        lists.append(loc)
+        cums.append(cum)
+    loc, cum = torch.stack(lists), torch.stack(cums)
+    if send is not None:
+        # the search's rule: prefix length = max over (query, shard) of the local rows with distance <= global T
+        tot = cum.sum(0)
+        T = (tot[:, 1:] >= k).int().argmax(dim=1)
+        need = int(torch.gather(cum, 2, (T + 1).view(1, Q, 1).expand(G, Q, 1).long()).max().item())
+        send = max(1, min(kin, need))
+        loc = loc[:, :, :send].contiguous()
+    mi, md = H.topk_merge_cum(loc, cum, per, k, nbits)
+    assert torch.equal(mi, full_idx) and torch.equal(md, full_d)
+
+
 def test_full_size_properties_c1():
     """Q=2048, N=25000, 64 bit, k=5000 (BASELINE c1): properties instead of a 51M-entry oracle."""
     Q, N, nbits, k = 2048, 25000, 64, 5000

@@ -52,6 +52,17 @@ def _fake_merge(idx_in, dist_in, k, nbits):
     return torch.gather(ids, 1, order), torch.gather(key, 1, order).to(torch.uint8)
 
 
+def _fake_merge_cum(idx_local, cum, shard_rows, k, nbits):
+    """Expand the compact form (16-bit local rows + per-shard cumulative histograms) and merge as above."""
+    G, Q, kin = idx_local.shape
+    ids = (idx_local.long() & 0xffff) + (torch.arange(G) * shard_rows).view(G, 1, 1)
+    pos = torch.arange(kin).view(1, 1, kin)
+    # distance of position p of a sorted list = number of boundaries cum[1:] that are <= p
+    d = (cum[:, :, 1:nbits + 2].unsqueeze(-1) <= pos.unsqueeze(2)).sum(2)
+    d = torch.where(pos < cum[:, :, nbits + 1:nbits + 2].clamp(max=kin), d, torch.full_like(d, nbits + 1))
+    return _fake_merge(ids.int(), d.to(torch.uint8), k, nbits)
+
+
 def _worker(rank, world, port, cases, nbits, ql, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "image-retrieval-wavelet_amd"))
@@ -59,7 +70,7 @@ def _worker(rank, world, port, cases, nbits, ql, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from wvhash import parallel, synth
     from wvhash.engine import hamming as H
-    H.hamming_topk, H.topk_merge = _fake_topk, _fake_merge          # CPU stand-ins for the two kernels
+    H.hamming_topk, H.topk_merge, H.topk_merge_cum = _fake_topk, _fake_merge, _fake_merge_cum   # CPU stand-ins for the kernels
     out = {}
     for n_db, k in cases:
         q_all, r = synth.random_codes(world * ql, n_db, nbits, seed=3)
