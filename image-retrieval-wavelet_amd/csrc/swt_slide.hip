@@ -527,6 +527,8 @@ static int launch_slide(const void *in, void *out, SlideGeom g, const float *lo,
     g.nxcd = xenv ? std::max(1, atoi(xenv)) : 8;
     if (grid < planes) grid -= grid % g.nxcd;      // persistent launch: same number of workgroups on every XCD
     if (grid <= 0 || grid % g.nxcd) g.nxcd = 1, grid = std::min<int64_t>(planes, (int64_t)num_cu * per_cu);
+    constexpr bool kHasStampBuild = (L == 4 && NLEV == 3) || (L == 2 && NLEV == 1);   // the two shipped configs
+    if constexpr (kHasStampBuild)
     if (getenv("WV_SWT_STAMPS")) {   // diagnostic build: run once, print where each role's cycles go
         auto kstamp = k_swt_slide<L, NLEV, R, TH, NT, MINW, InT, LAYOUT, BF16, true>;
         if (lds > 64 * 1024)
@@ -576,9 +578,17 @@ static int slide_types(const void *in, int in_dtype, void *out, const SlideGeom 
 #undef WV_GO
 }
 
+// (taps, levels) with a sliding instantiation: the shipped configs (haar L1 = c0, db2 L3 = c1), the other levels of
+// the 2- and 4-tap wavelets, and level 1 of the 8- and 10-tap wavelets the studies sweep (db4, bior4.4).  Everything
+// else (and shapes outside the window below) runs on swt_fused.hip / swt.hip.
+static bool slide_config(int L, int n)
+{
+    return ((L == 2 || L == 4) && n >= 1 && n <= 3) || ((L == 8 || L == 10) && n == 1);
+}
+
 bool swt_slide_covers(int L, int n, int W, int H)
 {
-    return ((L == 4 && n == 3) || (L == 2 && n == 1)) && (W % 4) == 0 && W <= 256 && W >= 40 && H >= 40;
+    return slide_config(L, n) && (W % 4) == 0 && W <= 256 && W >= 40 && H >= 40;
 }
 
 int swt_slide_launch(const void *in, int in_dtype, int in_layout, void *out, int out_dtype, int B, int C, int H,
@@ -586,8 +596,10 @@ int swt_slide_launch(const void *in, int in_dtype, int in_layout, void *out, int
 {
     SlideGeom g{};
     g.B = B; g.C = C; g.H = H; g.W = W; g.in_layout = in_layout; g.out_bf16 = out_dtype == WV_DT_BF16;
-    if (L == 4 && n == 3) return slide_types<4, 3, 16, 16, 256, 4>(in, in_dtype, out, g, lo, hi, st);
-    if (L == 2 && n == 1) return slide_types<2, 1, 16, 16, 256, 4>(in, in_dtype, out, g, lo, hi, st);
+#define WV_CFG(LL, NN) if (L == LL && n == NN) return slide_types<LL, NN, 16, 16, 256, 4>(in, in_dtype, out, g, lo, hi, st)
+    WV_CFG(4, 3); WV_CFG(2, 1);
+    WV_CFG(4, 1); WV_CFG(4, 2); WV_CFG(2, 2); WV_CFG(2, 3); WV_CFG(8, 1); WV_CFG(10, 1);
+#undef WV_CFG
     return 1;
 }
 

@@ -37,11 +37,12 @@ def main():
     a = ap.parse_args()
     Q, N = a.q, a.n
     if "swt" in a.what:
-        img = torch.randint(0, 256, (Q, 224, 224, 3), dtype=torch.uint8, device="cuda")
+        nhwc = bool(os.environ.get("SWT_NHWC"))          # default: planar [Q,3,224,224] like bench.py
+        img = torch.randint(0, 256, (Q, 224, 224, 3) if nhwc else (Q, 3, 224, 224), dtype=torch.uint8, device="cuda")
         for tile in os.environ.get("SWT_TILES", "default").split(";"):
             if tile != "default":
                 os.environ["WV_SWT_TILE"] = tile
-            ms = timeit(lambda: swt2d(img, a.wavelet, a.level, channels_last=True), a.reps)
+            ms = timeit(lambda: swt2d(img, a.wavelet, a.level, channels_last=nhwc), a.reps)
             gb = Q * (3 * 224 * 224 * (1 + 16)) / 1e9
             print(f"swt {a.wavelet} L{a.level} tile={tile}: {ms:.3f} ms  {gb / ms * 1e3:.0f} GB/s  {Q / ms * 1e3:.0f} img/s", flush=True)
     q, r = synth.random_codes(Q, N, 64, 0)
