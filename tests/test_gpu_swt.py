@@ -34,7 +34,10 @@ def run_hip(img_bhwc, wl, lev, channels_last, as_float=False, out_dtype=torch.fl
 CASES = [("haar", 1, 32, 32), ("haar", 2, 64, 48), ("haar", 3, 224, 224), ("db2", 1, 40, 56),
          ("db2", 2, 64, 64), ("db2", 3, 224, 224), ("db2", 3, 64, 256), ("db4", 1, 224, 224),
          ("db4", 2, 96, 96), ("bior4.4", 1, 224, 224), ("bior4.4", 2, 64, 32), ("db2", 3, 8, 8),
-         ("haar", 1, 2, 4), ("db4", 3, 32, 32), ("db2", 3, 512, 384)]
+         ("haar", 1, 2, 4), ("db4", 3, 32, 32), ("db2", 3, 512, 384),
+         # every (taps, levels) pair the sliding kernel is instantiated for, at shapes inside and at the edge of its window
+         ("haar", 2, 224, 224), ("db2", 1, 224, 224), ("db2", 2, 224, 224), ("db2", 2, 40, 256), ("haar", 3, 48, 40),
+         ("db4", 1, 40, 40), ("bior4.4", 1, 56, 256), ("haar", 1, 224, 224)]
 
 
 @pytest.mark.parametrize("wl,lev,H,W", CASES)
