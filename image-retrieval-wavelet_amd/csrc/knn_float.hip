@@ -240,6 +240,89 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_pass(const float *__res
     }
 }
 
+// Selection before sorting (k <= N/2): the full LSD sort moves every one of the N (key, index) pairs six times,
+// but only the k best are wanted.  One workgroup per row finds the k-th smallest key tau by radix selection on the
+// order-preserving 32-bit key (three histogram passes over 11 + 11 + 10 bits, coalesced reads of the score row),
+// then compacts -- in index order, i.e. stably -- the items with key < tau plus the first few items with key == tau
+// that fill up to exactly k, straight into the column image the radix passes read.  The six passes then sort k
+// items instead of N.  Same result as the full sort: ascending (key, index).
+constexpr int kSelBins = 2048;
+__global__ __launch_bounds__(256) void k_select_compact(const float *__restrict__ S, uint2 *__restrict__ dst, int64_t N,
+                                                        int k, int Ck, uint32_t ck_magic, int descending)
+{
+    __shared__ uint32_t hist[kSelBins];
+    __shared__ uint32_t wpart[8];
+    __shared__ uint32_t sel[2];          // chosen bin, items before it
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int64_t row = blockIdx.x;
+    const float *Srow = S + row * N;
+    uint2 *drow = dst + row * (int64_t)Ck * kRadixThreads;
+    uint32_t prefix = 0, mask = 0, remaining = (uint32_t)k;   // looking for the remaining-th smallest among the matches
+    const int shifts[3] = {21, 10, 0};
+    const int nbins[3] = {2048, 2048, 1024};
+    for (int pass = 0; pass < 3; ++pass) {
+        const int shift = shifts[pass], nb = nbins[pass];
+        for (int i = tid; i < kSelBins; i += 256) hist[i] = 0;
+        __syncthreads();
+        for (int64_t i = tid; i < N; i += 256) {
+            const uint32_t key = float_to_key(Srow[i], descending);
+            if ((key & mask) == prefix)
+                __hip_atomic_fetch_add(&hist[(key >> shift) & (uint32_t)(nb - 1)], 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        // bin where the running count reaches `remaining`: thread t owns bins [t*per, (t+1)*per)
+        const int per = nb / 256;
+        uint32_t mine = 0;
+        for (int j = 0; j < per; ++j) mine += hist[tid * per + j];
+        const uint32_t incl = wave_incl_scan_u32(mine);
+        if (lane == 63) wpart[wv] = incl;
+        __syncthreads();
+        uint32_t before = incl - mine;
+        for (int w2 = 0; w2 < wv; ++w2) before += wpart[w2];
+        if (before < remaining && remaining <= before + mine) {   // exactly one thread
+            uint32_t run = before;
+            for (int j = 0; j < per; ++j) {
+                const uint32_t c = hist[tid * per + j];
+                if (remaining <= run + c) { sel[0] = (uint32_t)(tid * per + j); sel[1] = run; break; }
+                run += c;
+            }
+        }
+        __syncthreads();
+        prefix |= sel[0] << shift;
+        mask |= (uint32_t)(nb - 1) << shift;
+        remaining -= sel[1];
+        __syncthreads();
+    }
+    const uint32_t tau = prefix, need_eq = remaining;             // take every key < tau and the first need_eq keys == tau
+    // stable compaction, 256 consecutive items per step
+    uint32_t base_less = 0, base_eq = 0;
+    for (int64_t i0 = 0; i0 < N; i0 += 256) {
+        const int64_t i = i0 + tid;
+        uint32_t key = 0xffffffffu;
+        bool less = false, eq = false;
+        if (i < N) {
+            key = float_to_key(Srow[i], descending);
+            less = key < tau;
+            eq = key == tau;
+        }
+        const uint64_t ml = __ballot(less), me = __ballot(eq);
+        if (lane == 0) { wpart[wv] = (uint32_t)__popcll(ml); wpart[4 + wv] = (uint32_t)__popcll(me); }
+        __syncthreads();
+        uint32_t lb = base_less + (uint32_t)mbcnt(ml), eb = base_eq + (uint32_t)mbcnt(me);
+        for (int w2 = 0; w2 < wv; ++w2) { lb += wpart[w2]; eb += wpart[4 + w2]; }
+        const uint32_t tot_l = wpart[0] + wpart[1] + wpart[2] + wpart[3], tot_e = wpart[4] + wpart[5] + wpart[6] + wpart[7];
+        if (less || (eq && eb < need_eq)) {
+            const uint32_t pos = lb + min(eb, need_eq);           // survivors before this one, in index order
+            const uint32_t tq = Ck == 1 ? pos : __umulhi(pos, ck_magic);   // pos / Ck
+            drow[(int64_t)(pos - tq * Ck) * kRadixThreads + tq] = make_uint2(key, (uint32_t)i);
+        }
+        base_less += tot_l;
+        base_eq += tot_e;
+        __syncthreads();
+    }
+}
+
 static int64_t knn_chunk_rows(int Q, int64_t N)
 {
     // bound the scratch to about 2 GiB: per row N * (4 + 8 + 8) bytes
@@ -300,6 +383,20 @@ extern "C" int wv_knn_float(const float *q, const float *db, int Q, int64_t N, i
         const int npass = 6;
         const uint2 *src = bufA;
         uint2 *dst = bufA;
+        const bool select_first = (int64_t)k * 2 <= N && !getenv("WV_KNN_FULLSORT");
+        if (select_first) {
+            // radix-select the k best of every row, then sort only those (the images keep the N-sized pitch)
+            const int Ck = (int)ceil_div(k, kRadixThreads);
+            const uint32_t ck_magic = Ck <= 1 ? 0u : (uint32_t)(((1ull << 32) + Ck - 1) / Ck);
+            hipLaunchKernelGGL(k_select_compact, dim3(qc), dim3(256), 0, st, S, bufB, N, k, Ck, ck_magic, descending);
+            for (int p = 0; p < npass; ++p) {
+                src = (p & 1) ? bufA : bufB;
+                dst = (p & 1) ? bufB : bufA;
+                hipLaunchKernelGGL(k_radix_pass, dim3(qc), dim3(kRadixThreads), 0, st, S, src, dst, (int64_t)k, Ck, ck_magic,
+                                   p * kRadixBits, 0, p == npass - 1, k, descending, idx + q0 * k, val + q0 * k);
+            }
+            continue;
+        }
         for (int p = 0; p < npass; ++p) {
             src = (p & 1) ? bufA : bufB;
             dst = (p & 1) ? bufB : bufA;
