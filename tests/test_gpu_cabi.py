@@ -89,3 +89,17 @@ def test_error_codes_on_the_gpu():
     assert lib.wv_map_at_k(_lib.ptr(idx), 2, 0, _lib.ptr(q), _lib.ptr(q), 1, _lib.ptr(idx), None, sp()) == -22
     assert lib.wv_knn_float(_lib.ptr(q), _lib.ptr(q), 2, 2, 6, 0, 1, _lib.ptr(idx), _lib.ptr(idx), _lib.ptr(q), 8, sp()) == -22
     assert b"multiple of 4" in lib.wv_last_error()
+
+
+def test_native_consumer_without_torch_or_python():
+    """tests/native/cabi_smoke: a plain HIP-runtime program linking libwvhash.so -- the boundary carries no torch
+    types.  Built by __graft_entry__.build() (make -C tests/native); checks SWT, ranking and AP on the host."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "native", "cabi_smoke")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "tests", "native")])
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "cabi_smoke ok" in res.stdout
