@@ -54,6 +54,7 @@ struct SlideGeom {
     int nrun;       // runs per row = ceil(W / R)
     int in_layout;
     int out_bf16;
+    int coal;       // planar uint8, W % 16 == 0: producers load every pixel once, coalesced (see the producer role)
     int nxcd;       // 8: workgroups w, w+8, ... (one XCD, hardware round-robin) share images; 1: plain striding
     unsigned long long *stamps;   // diagnostic build only
 };
@@ -318,8 +319,23 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
     }
     if (is_h) {
         // ------------------------------------------------------------------ producer: pass H
-        const int rr = t / g.nrun, j = t - rr * g.nrun;
-        const bool active = t < TH * g.nrun;
+        // (row, run) of this producer thread.  Coalesced mode (planar uint8, W % 16 == 0) keeps the runs of one row
+        // inside one wave -- 64 / nrun rows per wave -- so that neighbouring runs can hand over their pixels with
+        // ds_bpermute: each thread then issues ONE 16-byte load per chunk and every input byte is read exactly once
+        // (the strided form touches each cache line of its 40-pixel window ten times).
+        int rr = t / g.nrun, j = t - rr * g.nrun;
+        bool active = t < TH * g.nrun;
+        int lane_left = 0, lane_right = 0, rr_ld = 0;
+        if (g.coal) {
+            const int l = t & 63, rpw = 64 / g.nrun, lr = l / g.nrun;
+            j = l - lr * g.nrun;
+            rr = (t >> 6) * rpw + lr;
+            active = lr < rpw && rr < TH;
+            rr_ld = min(rr, TH - 1);                                             // spare lanes load a valid row too
+            lane_left = (lr * g.nrun + (j == 0 ? g.nrun - 1 : j - 1)) * 4;       // byte addresses for ds_bpermute
+            lane_right = (lr * g.nrun + (j == g.nrun - 1 ? 0 : j + 1)) * 4;      // (periodic: the row wraps onto itself)
+            if (lr >= rpw) lane_left = lane_right = 0;
+        }
         for (int q = wg_in_xcd; q < nq; q += wgs_per_xcd) {
             const int m = q / g.C, c = q - m * g.C, b = xcd + g.nxcd * m, pc = b * g.C + c;
             const InT *img = LAYOUT == 0 ? in + (size_t)pc * band : in + (size_t)b * band * 3;
@@ -334,9 +350,36 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
                 for (int k = 0; k < NG; ++k)
                     raw[k] = s_fetch4<InT, LAYOUT>(img, row + (uint32_t)swrap1(gx0 + 4 * k, W), c);
             };
-            if (active) fetch(0);
+            constexpr bool CAN_COAL = sizeof(InT) == 1 && LAYOUT == 0 && R == 16 && NG * 4 - HBa <= 32;
+            uint32_t own[4] = {0, 0, 0, 0};
+            auto issue_row = [&](int chunk) {       // every lane of the wave (the exchange below reads all of them)
+                int y = chunk * TH + rr_ld - HB;
+                y = y >= H ? y - H : y;
+                const uint4 v4 = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(img) +
+                                                                  (size_t)swrap1(y, H) * W + j * R);
+                own[0] = v4.x; own[1] = v4.y; own[2] = v4.z; own[3] = v4.w;
+            };
+            const bool coal = CAN_COAL && g.coal;   // uniform
+            if (coal) issue_row(0);
+            else if (active) fetch(0);
             for (int k = 0; k < nchunks; ++k) {
                 WV_STAMP(st0);
+                if constexpr (CAN_COAL) {
+                    if (coal) {
+                        // window of run j = pixels [16j - HBa, 16j - HBa + 4 NG): left neighbour | own | right neighbour
+#pragma unroll
+                        for (int kk = 0; kk < NG; ++kk) {
+                            const int gpx = 4 * kk - HBa;                      // compile-time after unrolling
+                            if (gpx < 0)
+                                raw[kk].d[0] = (uint32_t)__builtin_amdgcn_ds_bpermute(lane_left, (int)own[(gpx + 16) / 4]);
+                            else if (gpx < 16)
+                                raw[kk].d[0] = own[gpx / 4];
+                            else
+                                raw[kk].d[0] = (uint32_t)__builtin_amdgcn_ds_bpermute(lane_right, (int)own[(gpx - 16) / 4]);
+                        }
+                        if (k + 1 < nchunks) issue_row(k + 1);                 // flies during this chunk's arithmetic
+                    }
+                }
                 if (active) {
                     float v[NG * 4];
 #pragma unroll
@@ -345,7 +388,7 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
                         v[4 * q + 0] = p4.x; v[4 * q + 1] = p4.y; v[4 * q + 2] = p4.z; v[4 * q + 3] = p4.w;
                     }
                     WV_STAMP(st1);
-                    if (k + 1 < nchunks) fetch(k + 1);     // next chunk's pixels fly during the arithmetic
+                    if (k + 1 < nchunks && !coal) fetch(k + 1);     // next chunk's pixels fly during the arithmetic
                     WV_STAMP(st4);
                     // in-place cascade on v[off ..): element i of the run lives at v[i + off]
                     constexpr int off = HBa - HB;
@@ -523,6 +566,9 @@ static int launch_slide(const void *in, void *out, SlideGeom g, const float *lo,
     const int per_cu = env && atoi(env) > 0 ? atoi(env) : std::min(by_lds, std::max(1, MINW * 256 / (2 * NT)));
     const int64_t planes = (int64_t)g.B * g.C;
     int64_t grid = std::min<int64_t>(planes, (int64_t)num_cu * per_cu);
+    const char *cenv = getenv("WV_SWT_COAL");
+    g.coal = std::is_same<InT, uint8_t>::value && LAYOUT == 0 && R == 16 && g.W % 16 == 0 && g.nrun <= 16 &&
+             (int64_t)g.H * g.W % 16 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && !(cenv && atoi(cenv) == 0);
     const char *xenv = getenv("WV_SWT_XCD");
     g.nxcd = xenv ? std::max(1, atoi(xenv)) : 8;
     if (grid < planes) grid -= grid % g.nxcd;      // persistent launch: same number of workgroups on every XCD
