@@ -270,14 +270,29 @@ __global__ __launch_bounds__(256, 2) void k_gemm_panel(const float *__restrict__
     for (int i = 0; i < A4; ++i) *reinterpret_cast<f32x4 *>(sm + so_a[i]) = ra[i];
 #pragma unroll
     for (int i = 0; i < B4; ++i) *reinterpret_cast<f32x4 *>(sm + so_b[i]) = rb[i];
-    __syncthreads();
     const int nk = kchunk / BK;
+    // Staging pipeline (one register set): tile t+1 travels global -> registers during tile t-1's MFMAs, is written to
+    // the free LDS stage at the START of tile t (that stage was last read before the barrier that ended tile t-1),
+    // and the registers are re-issued for tile t+2 at once -- every load has a whole tile of MFMAs to land, and the
+    // LDS writes sit in the shadow of the previous tile's last MFMAs instead of in front of the barrier.
+    if (nk > 1) {
+#pragma unroll
+        for (int i = 0; i < A4; ++i) ra[i] = *reinterpret_cast<const f32x4 *>(ga[i] + BK);
+#pragma unroll
+        for (int i = 0; i < B4; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(gb[i] + BK);
+    }
+    __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         float *cur = sm + (kt & 1) * STAGE;
         float *nxt = sm + ((kt & 1) ^ 1) * STAGE;
-        const bool more = kt + 1 < nk;
-        if (more) {
-            const int k0 = (kt + 1) * BK;
+        if (kt + 1 < nk) {
+#pragma unroll
+            for (int i = 0; i < A4; ++i) *reinterpret_cast<f32x4 *>(nxt + so_a[i]) = ra[i];
+#pragma unroll
+            for (int i = 0; i < B4; ++i) *reinterpret_cast<f32x4 *>(nxt + so_b[i]) = rb[i];
+        }
+        if (kt + 2 < nk) {
+            const int k0 = (kt + 2) * BK;
 #pragma unroll
             for (int i = 0; i < A4; ++i) ra[i] = *reinterpret_cast<const f32x4 *>(ga[i] + k0);
 #pragma unroll
@@ -310,12 +325,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_panel(const float *__restrict__
             for (int b = 0; b < 3; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv[b].z, acc[b], 0, 0, 0);
 #pragma unroll
             for (int b = 0; b < 3; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[b].w, acc[b], 0, 0, 0);
-        }
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < A4; ++i) *reinterpret_cast<f32x4 *>(nxt + so_a[i]) = ra[i];
-#pragma unroll
-            for (int i = 0; i < B4; ++i) *reinterpret_cast<f32x4 *>(nxt + so_b[i]) = rb[i];
         }
         __syncthreads();
     }
