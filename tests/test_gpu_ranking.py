@@ -341,3 +341,18 @@ def test_cumulative_histogram_output():
         assert torch.equal(cum.cpu().long(), ref)
         ri, rd = ranking.hamming_topk_stable(q, r, k)
         assert torch.equal(idx.cpu().long(), ri) and torch.equal(d.cpu().long(), rd)
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine"])
+def test_float_knn_select_path_with_ties_across_the_threshold(metric):
+    """k <= N/2 takes the radix-select path: duplicated rows put equal scores on both sides of the k-th position;
+    the k best must come out in ascending (score, index) order like the stable oracle."""
+    g = torch.Generator().manual_seed(9)
+    Q, N, D, k = 11, 3000, 8, 700
+    q = torch.randint(-2, 3, (Q, D), generator=g).float()
+    r = torch.randint(-2, 3, (N, D), generator=g).float()
+    r[N // 2:] = r[: N - N // 2].clone()
+    gi, gd = get_knn(r, q, k, False, distance_metric=metric)
+    sd, si = ranking.knn_stable(r, q, k, metric)
+    assert torch.equal(gi.cpu().long(), si.long())
+    assert torch.allclose(gd.cpu(), sd, rtol=1e-6, atol=1e-6)
