@@ -212,6 +212,12 @@ def kernel_table(p, reps, swt_ms_live):
         rows.append(("wv_hamming_dist[k_hamming_dist u8 matrix]", "hbm", Q * N_DB + (Q + N_DB) * NBITS // 8,
                      time_stage(lambda: p.Hm.hamming_dist(packed, p.db_packed_full), reps),
                      "not part of the step; timed alone, back to back"))
+        # the same kernel on the query set of an 8-GPU search (every rank ranks all 8 x 2048 queries): 410 MB per launch
+        q8 = packed.repeat(8, 1).contiguous()
+        rows.append(("wv_hamming_dist[same kernel, 16384 queries] (not in the step)", "hbm",
+                     8 * Q * N_DB + (8 * Q + N_DB) * NBITS // 8,
+                     time_stage(lambda: p.Hm.hamming_dist(q8, p.db_packed_full), reps), "timed alone, back to back"))
+        del q8
     out = []
     for name, bound, work, ms, how in rows:
         if bound == "hbm":
