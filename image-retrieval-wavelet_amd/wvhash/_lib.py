@@ -53,6 +53,8 @@ SIGNATURES = {
     "wv_dwt_out_len": (_i, [_i, _i, _i]),
     "wv_dwt2d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "wv_dwt2d_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _fp, _fp, _i, _vp, _sz, _vp]),
+    "wv_lifting2d_workspace_bytes": (_sz, [_i64, _i, _i]),
+    "wv_lifting2d_forward": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "wv_pack_bits": (_i, [_vp, _i64, _vp, _i64, _i, _i, _vp, _vp]),
     "wv_bit_counts": (_i, [_vp, _i64, _i, _vp, _vp]),
     "wv_hamming_dist": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _i, _vp]),

@@ -2,6 +2,8 @@ from .custom_transforms import SWTTransform, DWTTransform, RawStackTransform, Ba
 from .functional import swt2d, dwt2d, rawstack
 from .wavelets import get_filters, wavelist
 from .pil_ops import Resize, CenterCrop, Compose, build_transform
+from .lifting import CustomTransform, ResizeSubBands, HaarLifting, Cdf97Lifting
 
 __all__ = ["SWTTransform", "DWTTransform", "RawStackTransform", "BaseWaveletTransform", "swt2d",
-           "dwt2d", "rawstack", "get_filters", "wavelist", "Resize", "CenterCrop", "Compose", "build_transform"]
+           "dwt2d", "rawstack", "get_filters", "wavelist", "Resize", "CenterCrop", "Compose", "build_transform", "CustomTransform", "ResizeSubBands", "HaarLifting",
+           "Cdf97Lifting"]

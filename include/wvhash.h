@@ -76,6 +76,15 @@ int wv_dwt2d_forward(const void *in, int in_dtype, int in_layout, float *out, in
                      int level, const float *dec_lo, const float *dec_hi, int flen, void *workspace,
                      size_t workspace_bytes, void *stream);
 
+/* One level of the legacy lifting-scheme DWT behind CustomTransform (custom_transforms.py:14-55,90-117;
+ * wavelets/haar.py:21-86, wavelets/cdf_97.py:33-133): basis 0 = haar, 1 = cdf 9/7, zero-padded lifting steps,
+ * 2-D scales (1/2, 1, 1, sqrt 2).  in: float32 [planes][H][W], H and W even (the caller pads like
+ * HaarLifting / Cdf97Lifting do);  ll: [planes][H/2][W/2];  hi: [planes][3][H/2][W/2] = (LH, HL, HH).
+ * Bit-identical to the reference's float32 torch ops (every product and sum rounded separately, same order). */
+size_t wv_lifting2d_workspace_bytes(int64_t planes, int H, int W);
+int wv_lifting2d_forward(const float *in, int64_t planes, int H, int W, int basis, float *ll, float *hi,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Bit packing of +-1 hash codes and multi-hot labels.
  * Codes come out of torch.sign(logits) (multi_dino_attention.py:833) as fp32 in {-1,+1};
