@@ -147,3 +147,20 @@ def test_rawstack_batched():
     # numpy's IEEE x/255 (torch on the GPU multiplies by a reciprocal: 1 ulp off)
     ref = img.cpu().numpy().astype(np.float32).transpose(0, 3, 1, 2) / 255.0
     assert np.array_equal(y.cpu().numpy(), np.repeat(ref[:, :, None], 4, axis=2))
+
+
+def test_haar_level1_kernel_against_reference_made_lifting_vectors():
+    """c0's transform (haar, level 1) tied to numbers the reference itself produced: its decimated Haar lifting output
+    (tests/golden/lifting_golden.npz) is the stationary transform at even shifts, up to the lifting scale factors
+    (see tests/test_oracle_lifting.py)."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "lifting_golden.npz"))
+    name = "haar_224"
+    shape, seed = tuple(gold[f"{name}/shape"]), int(gold[f"{name}/seed"])
+    x = torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+    y = swt2d(x.cuda(), "haar", 1).cpu().numpy()[0, 0]            # [4, 224, 224]
+    ll, hi = gold[f"{name}/l0/ll"][0, 0], gold[f"{name}/l0/hi"][0, 0]
+    ev = y[:, 0::2, 0::2]
+    t = 2e-6 * float(x.abs().max())
+    assert np.abs(ev[0] - 2 * ll).max() < t and np.abs(ev[1] + hi[0]).max() < t
+    assert np.abs(ev[2] + hi[1]).max() < t and np.abs(ev[3] - hi[2] / np.sqrt(2)).max() < t

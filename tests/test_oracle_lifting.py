@@ -46,3 +46,22 @@ def test_custom_transform_output_layouts():
     c = np.full((1, 8, 8), 0.75, np.float32)
     z = lifting_np.custom_transform(c, 1, "haar")
     assert np.allclose(z[0, 0], 0.75, atol=1e-6) and np.abs(z[0, 1:]).max() < 1e-6
+
+
+def test_haar_swt_level1_is_anchored_to_reference_made_lifting_vectors(gold):
+    """Cross-check of the (PyWavelets-unpinned) SWT restatement against numbers the REFERENCE produced: the decimated
+    Haar transform is the stationary one sampled at even shifts.  With the reference's lifting scales
+    (LL * 1/2, LH, HL * 1, HH * sqrt 2; sign of the detail filters flipped: d = (odd - even)/sqrt 2)
+        cA[2i,2j] = 2 LL[i,j],  cH[2i,2j] = -LH[i,j],  cV[2i,2j] = -HL[i,j],  cD[2i,2j] = HH[i,j] / sqrt 2."""
+    from oracle import swt_np
+    name = "haar_224"
+    shape, seed = tuple(gold[f"{name}/shape"]), int(gold[f"{name}/seed"])
+    x = torch.randn(shape, generator=torch.Generator().manual_seed(seed)).numpy()[0, 0]
+    swt = swt_np.swt2_level_n(x, "haar", 1)                       # [4, 224, 224]: cA, cH, cV, cD
+    ll, hi = gold[f"{name}/l0/ll"][0, 0], gold[f"{name}/l0/hi"][0, 0]
+    ev = swt[:, 0::2, 0::2]
+    tol = 2e-6 * np.abs(x).max()
+    assert np.abs(ev[0] - 2 * ll).max() < tol
+    assert np.abs(ev[1] + hi[0]).max() < tol
+    assert np.abs(ev[2] + hi[1]).max() < tol
+    assert np.abs(ev[3] - hi[2] / np.sqrt(2)).max() < tol
