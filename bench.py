@@ -98,6 +98,9 @@ class Pipeline:
         self.Hm = Hm
         self.db_codes_cpu = db_codes
         self.marks, self.marks_all = None, False
+        # sharded search: prefix length of the list exchange.  None = sized exactly with one host read per step
+        # (first warm-up step); afterwards the learned length + headroom, no host read, verified after the timed loop
+        self.send_hint, self.needs, self.kin = None, [], min(TOPK, shard_bounds(N_DB, world, rank)[2])
 
     # -- the stages (each one C-ABI call) ---------------------------------------------------
     def stage_swt(self):
@@ -113,7 +116,18 @@ class Pipeline:
 
     def stage_rank(self, packed):
         from wvhash.parallel import sharded_hamming_topk
-        return sharded_hamming_topk(packed, self.db_shard, NBITS, TOPK, N_DB, workspace=self.ws)
+        idx, d, need = sharded_hamming_topk(packed, self.db_shard, NBITS, TOPK, N_DB, workspace=self.ws,
+                                            send_hint=self.send_hint, return_need=True)
+        if need is not None:
+            self.needs.append(need)
+        return idx, d
+
+    def learn_send_hint(self):
+        """After an exactly-sized step: exchange need + 12 % headroom from now on (rounded up to 64 entries)."""
+        if self.world > 1 and self.needs:
+            need = int(torch.stack([n.reshape(()) for n in self.needs]).max().item())
+            self.send_hint = min(self.kin, (int(need * 1.12) + 63) // 64 * 64)
+        self.needs = []
 
     def stage_map(self, idx):
         return self.Hm.map_at_k(idx, self.qlab, self.dblab)
@@ -204,6 +218,14 @@ def kernel_table(p, reps, swt_ms_live):
                      (Q + N_DB) * NBITS // 8 + Q * TOPK * 5, st["rank1"], how))
         rows.append(("wv_map_at_k", "hbm", Q * TOPK * 4 + (Q + N_DB) * 8 + Q * 8, st["map1"], how))
         from wvhash.transforms import swt2d
+        bm = torch.empty((4, Q, 3, H, W), dtype=torch.float32, device=p.dev)
+        rows.append(("wv_swt2d_forward_ex[same kernel, band-major output [4,Q,3,224,224]: what the models consume] "
+                     "(not in the step)", "hbm", swt_bytes,
+                     time_stage(lambda: swt2d(p.images, WAVELET, LEVEL, out=bm, band_major=True), reps),
+                     "timed alone, back to back"))
+        rows.append(("wv_swt2d_forward[same kernel, reference layout] (not in the step)", "hbm", swt_bytes,
+                     time_stage(lambda: swt2d(p.images, WAVELET, LEVEL, out=p.bands), reps), "timed alone, back to back"))
+        del bm
         nhwc = p.images.permute(0, 2, 3, 1).contiguous()
         rows.append(("wv_swt2d_forward[same, interleaved [Q,224,224,3] input] (not in the step)", "hbm", swt_bytes,
                      time_stage(lambda: swt2d(nhwc, WAVELET, LEVEL, channels_last=True, out=p.bands), reps),
@@ -229,6 +251,19 @@ def kernel_table(p, reps, swt_ms_live):
     return out
 
 
+def stream_ceilings(device):
+    """What a plain streaming kernel reaches on THIS box (report the achievable ceiling beside the 8 TB/s
+    spec): a 1 GiB float4 copy (read + write) and a 1 GiB fill (write only -- the SWT kernel is 94 % writes)."""
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device=device)
+    b = torch.empty(n, dtype=torch.float32, device=device)
+    copy_ms = time_stage(lambda: b.copy_(a), 10)
+    fill_ms = time_stage(lambda: b.fill_(1.0), 10)
+    del a, b
+    return {"copy_ceiling_gbs": round(2 * n * 4 / (copy_ms * 1e-3) / 1e9, 1),
+            "store_ceiling_gbs": round(n * 4 / (fill_ms * 1e-3) / 1e9, 1)}
+
+
 def load_traffic(kernel_name):
     """HBM bytes per launch from the committed rocprofv3 --pmc summary (profiles/), if present."""
     path = os.path.join(ROOT, "profiles", "traffic_r01.json")
@@ -243,6 +278,42 @@ def load_traffic(kernel_name):
     return None
 
 
+_POOL_WORKER = r"""
+import sys, time
+root, path, wl, lev, i, n, reps, t_start = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), \
+    int(sys.argv[6]), int(sys.argv[7]), float(sys.argv[8])
+sys.path.insert(0, root)
+import numpy as np
+from oracle import swt_np                      # numpy + ctypes only: no torch, no GPU in this process
+imgs = np.ascontiguousarray(np.load(path, mmap_mode="r")[i::n])
+swt_np.c_transform_batch(imgs[:1], wl, lev)
+time.sleep(max(0.0, t_start - time.time()))    # all workers start together
+for _ in range(reps):
+    swt_np.c_transform_batch(imgs, wl, lev)    # one image, one channel at a time, like a DataLoader worker
+print(time.time(), len(imgs) * reps)
+"""
+
+
+def cpu_swt_pool(imgs_hwc, nproc, reps):
+    """The oracle's SWT on `nproc` single-threaded worker PROCESSES at once -- how the reference runs it
+    (DataLoader(num_workers=...), evaluate.py:79-91).  Fresh interpreters (no fork of this GPU-owning process)."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "imgs.npy")
+        np.save(path, imgs_hwc)
+        t_start = time.time() + 4.0
+        procs = [subprocess.Popen([sys.executable, "-c", _POOL_WORKER, ROOT, path, WAVELET, str(LEVEL), str(i),
+                                   str(nproc), str(reps), repr(t_start)], stdout=subprocess.PIPE, text=True)
+                 for i in range(nproc)]
+        outs = [pr.communicate()[0].split() for pr in procs]
+    if any(pr.returncode for pr in procs):
+        raise RuntimeError("cpu_baseline: an SWT worker process failed")
+    done = sum(int(o[1]) for o in outs)
+    wall = max(float(o[0]) for o in outs) - t_start
+    return done / wall, done
+
+
 def cpu_baseline(p):
     """The reference's op sequence on the host cores (oracle = CPU port), bounded sample."""
     from oracle import head_torch, ranking, swt_np
@@ -250,12 +321,15 @@ def cpu_baseline(p):
     # threads actually usable: the affinity mask, capped at the GPU box's 16-core share per GPU
     ncores = min(len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(ncores)
-    n_img, n_q = min(512, p.Q), min(2048, p.Q)          # ~8 s of SWT + ~3 s of ranking on one host socket
+    n_img, n_q = min(512, p.Q), min(2048, p.Q)
     imgs = np.ascontiguousarray(p.images[:n_img].permute(0, 2, 3, 1).cpu().numpy())   # HWC, as PIL hands them over
     swt_np.c_transform_batch(imgs[:2], WAVELET, LEVEL)
     t0 = time.perf_counter()
     swt_np.c_transform_batch(imgs, WAVELET, LEVEL)       # per image, per channel, like the DataLoader worker
-    t_swt = (time.perf_counter() - t0) / n_img
+    t_swt1 = (time.perf_counter() - t0) / n_img
+    reps = max(1, int(round(6.0 / (t_swt1 * n_img / ncores))))          # ~6 s of wall time for the pool
+    pool_rate, pool_done = cpu_swt_pool(imgs, ncores, reps)
+    t_swt = 1.0 / pool_rate
     sd = synth.head_state(EMBED, NQ, "concat", seed=0)
     feats = [f[:n_q].cpu() for f in p.feats]
     tail = synth.hash_tail_state(EMBED, NBITS, seed=1)
@@ -279,24 +353,51 @@ def cpu_baseline(p):
     per_img = t_swt + t_head + t_rank
     return {
         "value": round(1.0 / per_img, 2), "unit": "query images/s", "cores": ncores, "kind": "port",
-        "sample": f"{n_img} images SWT db2 L3 (C oracle, 1 thread, per image/channel like a DataLoader worker) + "
-                  f"{n_q} queries head/hash + per-query ranking loop (torch CPU, {ncores} threads), "
-                  f"N_db={N_DB}, k={TOPK}; value = 1 / (sum of per-image stage times)",
-        "ms_per_image": {"swt": round(t_swt * 1e3, 3), "head_hash": round(t_head * 1e3, 4),
-                         "rank_map": round(t_rank * 1e3, 3)},
+        "sample": f"SWT db2 L3: the C oracle in {ncores} single-threaded worker processes at once ({pool_done} images, "
+                  f"per image/channel like DataLoader workers); {n_q} queries head/hash + the reference's per-query "
+                  f"ranking loop (torch CPU, {ncores} threads), N_db={N_DB}, k={TOPK}; "
+                  f"value = 1 / (sum of per-image stage times)",
+        "ms_per_image": {"swt_pool": round(t_swt * 1e3, 4), "swt_one_process": round(t_swt1 * 1e3, 3),
+                         "head_hash": round(t_head * 1e3, 4), "rank_map": round(t_rank * 1e3, 3)},
+        "swt_images_per_s": {"one_process": round(1.0 / t_swt1, 1), f"{ncores}_processes": round(pool_rate, 1)},
         "map_at_k_cpu_sample": round(m_ref, 6),
         "max_abs_ap_diff_gpu_vs_cpu": float(np.abs(ap_gpu - np.asarray(ap_ref)).max()),
     }
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks as fresh child
+    processes (torch.distributed.run, one per GPU) and exit with their status.  This process has not touched
+    the GPU (no HIP call, device_count() does not initialise it) and never does -- it only waits."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "WV_DIST_BACKEND" not in env and torch.cuda.device_count() < args.gpus:
+        # fewer GPUs than ranks (a 1-GPU box): RCCL refuses two ranks on one device, so rehearse the N-rank path
+        # with CPU-staged gloo collectives; the JSON line says so ("backend")
+        env["WV_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
     local_rank = local_rank % max(torch.cuda.device_count(), 1)   # rehearsal: several ranks on one GPU
@@ -317,9 +418,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    out = p.step()                     # untimed: sizes the list exchange exactly (one host read), compiles nothing
+    p.learn_send_hint()
     for _ in range(args.warmup):
         out = p.step()
     barrier()
+    p.needs = []
     p.marks = []                       # one HIP event before and after the SWT launch of every timed step
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -327,6 +431,17 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     swt_marks, p.marks = p.marks, None
+    exchange = None
+    if world > 1:
+        from wvhash.parallel import exchange_ok
+        bad = torch.tensor([0 if exchange_ok(p.needs, p.send_hint, p.kin) else 1], dtype=torch.int32,
+                           device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)             # every rank learns whether any rank fell short
+        ok = int(bad.item()) == 0
+        exchange = {"prefix_entries": p.send_hint, "max_possible": p.kin, "verified_exact": ok}
+        if not ok:
+            raise SystemExit(f"a timed step needed a longer list prefix than the hinted {p.send_hint}: the results of "
+                             "that step are not exact, refusing to report a number")
     swt_ms = [a[1].elapsed_time(b[1]) for a, b in zip(swt_marks[0::2], swt_marks[1::2])]
     swt_ms_live = sum(swt_ms) / max(len(swt_ms), 1)
     ap = out[3]
@@ -358,6 +473,10 @@ def main():
             "wavelet": WAVELET, "level": LEVEL,
             "arithmetic": "fp32 SWT and head (fp32 MFMA), 64-bit popcount ranking, AP in fp32/fp64",
             "streams": args.streams,
+            "backend": (("rccl" if dist.get_backend() == "nccl" else
+                         f"{dist.get_backend()} (REHEARSAL: {world} ranks share {torch.cuda.device_count()} GPU(s), "
+                         "collectives staged through host memory)") if world > 1 else "none"),
+            "exchange": exchange,
             "parallelism": f"db row-sharded x{world}, all_gather(codes)+all_to_all(top-k lists)" if world > 1 else "single GPU",
         },
     }
@@ -367,7 +486,9 @@ def main():
                   key=lambda k: k["ms"])
         result["roofline"] = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"],
                               "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
-                              "traffic": load_traffic(dom["kernel"])}
+                              "traffic": load_traffic(dom["kernel"]),
+                              "traffic_source": "rocprofv3 --pmc passes committed under profiles/ (not measured in this run)"}
+        result["roofline"].update(stream_ceilings(device))
         result["kernels"] = kt
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(p)

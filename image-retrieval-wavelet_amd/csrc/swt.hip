@@ -602,6 +602,38 @@ extern "C" int wv_swt2d_forward(const void *in, int in_dtype, int in_layout, voi
     WV_FAIL(WV_ENOTSUP, "swt: dtype pair in=%d out=%d not supported", in_dtype, out_dtype);
 }
 
+extern "C" int wv_swt2d_forward_ex(const void *in, int in_dtype, int in_layout, void *out, int out_dtype,
+                                   int out_layout, int64_t band_stride, int B, int C, int H, int W, int level,
+                                   const float *dec_lo, const float *dec_hi, int flen, void *workspace,
+                                   size_t workspace_bytes, void *stream)
+{
+    if (out_layout == WV_BANDS_INNER)
+        return wv_swt2d_forward(in, in_dtype, in_layout, out, out_dtype, B, C, H, W, level, dec_lo, dec_hi, flen,
+                                workspace, workspace_bytes, stream);
+    WV_REQUIRE(out_layout == WV_BANDS_OUTER, "swt: bad output layout %d", out_layout);
+    WV_REQUIRE(in && out, "swt: null buffer");
+    WV_REQUIRE(dec_lo && dec_hi && flen >= 1, "swt: missing filter taps");
+    WV_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "swt: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
+    WV_REQUIRE(level >= 1 && level <= 12, "swt: level %d out of range", level);
+    WV_REQUIRE((H % (1 << level)) == 0 && (W % (1 << level)) == 0,
+               "swt: H=%d, W=%d must be multiples of 2^level=%d (PyWavelets raises ValueError here)",
+               H, W, 1 << level);
+    WV_REQUIRE(in_layout == WV_LAYOUT_NCHW || in_layout == WV_LAYOUT_NHWC, "swt: bad layout %d", in_layout);
+    WV_REQUIRE(B <= 65535 && C <= 65535, "swt: B and C must be <= 65535 per call");
+    WV_REQUIRE(band_stride >= (int64_t)B * C * H * W, "swt: band_stride %lld < B*C*H*W", (long long)band_stride);
+    WV_REQUIRE((in_dtype == WV_DT_U8 || in_dtype == WV_DT_F32) && (out_dtype == WV_DT_F32 || out_dtype == WV_DT_BF16),
+               "swt: dtype pair in=%d out=%d not supported", in_dtype, out_dtype);
+    // band-major output exists in the sliding kernel only (the shapes of the hot path); the caller re-lays the
+    // reference layout out for anything else
+    if (!swt_slide_covers(flen, level, W, H))
+        WV_FAIL(WV_ENOTSUP, "swt: band-major output is implemented by the sliding kernel only (W %% 4 == 0, 40 <= W <= 256, "
+                            "H >= 40, 2/4 taps at levels 1-3 or 8/10 taps at level 1)");
+    const int rc = swt_slide_launch(in, in_dtype, in_layout, out, out_dtype, B, C, H, W, level, dec_lo, dec_hi, flen,
+                                    (hipStream_t)stream, WV_BANDS_OUTER, band_stride);
+    if (rc > 0) WV_FAIL(WV_ENOTSUP, "swt: shape outside the sliding kernel's window");
+    return rc;
+}
+
 extern "C" int wv_rawstack_forward(const void *in, int in_dtype, int in_layout, void *out,
                                    int out_dtype, int B, int C, int H, int W, int copies,
                                    void *stream)

@@ -56,6 +56,10 @@ struct SlideGeom {
     int out_bf16;
     int coal;       // planar uint8, W % 16 == 0: producers load every pixel once, coalesced (see the producer role)
     int nxcd;       // 8: workgroups w, w+8, ... (one XCD, hardware round-robin) share images; 1: plain striding
+    // output addressing in elements: plane (b, c) starts at (b*C + c) * pstride, its band k at + k * bstride.
+    //   [B][C][4][H][W] (reference layout):  pstride = 4*H*W, bstride = H*W
+    //   [4][B][C][H][W] (band-major, each band one contiguous NCHW batch):  pstride = H*W, bstride = B*C*H*W
+    size_t pstride, bstride;
     unsigned long long *stamps;   // diagnostic build only
 };
 
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
         const int tp2 = ((t % R) / 2) * (4 * g.nrun) + (t / R) * 4 + 2 * (t & 1);   // PAIRED layout (floats)
         for (int q = wg_in_xcd; q < nq; q += wgs_per_xcd) {
             const int m = q / g.C, pc = (xcd + g.nxcd * m) * g.C + (q - m * g.C);
-            OutT *oplane = reinterpret_cast<OutT *>(out) + (size_t)pc * 4 * band;
+            OutT *oplane = reinterpret_cast<OutT *>(out) + (size_t)pc * g.pstride;
             float tail[PAIRED ? 1 : 2][PAIRED ? 1 : HALO];
             f32x2 tail2[PAIRED ? HALO : 1];
             if constexpr (PAIRED) {
@@ -470,15 +474,18 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
                             VS::prime_last(cur, tail2);
                         } else {
                             // byte offsets of this lane inside the plane's 4-band block (< 2^32, host check)
-                            const uint32_t o0 = (uint32_t)t * (uint32_t)sizeof(OutT), bb = band * (uint32_t)sizeof(OutT);
+                            // the four band rows are wave-uniform pointers (SGPR pairs, scalar adds): the band stride
+                            // may exceed 32 bits in the band-major layout
+                            const uint32_t o0 = (uint32_t)t * (uint32_t)sizeof(OutT);
+                            const size_t bs = g.bstride;
                             VS::last(cur, tail2, taps.lo, taps.hi, [&](int i, f32x2 a, f32x2 d) {
                                 const int y = y0 + i;
                                 if (y >= 0 && y < H) {
                                     OutT *orow = oplane + (size_t)y * W;   // uniform: lives in an SGPR pair
                                     store_row(orow, o0, (OutT)a.x);             // cA  = (row lo, col lo)
-                                    store_row(orow, o0 + bb, (OutT)d.x);        // cH  = (row lo, col hi)
-                                    store_row(orow, o0 + 2 * bb, (OutT)a.y);    // cV  = (row hi, col lo)
-                                    store_row(orow, o0 + 3 * bb, (OutT)d.y);    // cD  = (row hi, col hi)
+                                    store_row(orow + bs, o0, (OutT)d.x);        // cH  = (row lo, col hi)
+                                    store_row(orow + 2 * bs, o0, (OutT)a.y);    // cV  = (row hi, col lo)
+                                    store_row(orow + 3 * bs, o0, (OutT)d.y);    // cD  = (row hi, col hi)
                                 }
                             });
                         }
@@ -497,22 +504,24 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
                             VStep<L, NLEV, TH>::prime_last(cur, tail[pl]);
                         } else {
                             // byte offsets of this lane inside the plane's 4-band block (< 2^32, host check)
-                            const uint32_t off_lo = ((uint32_t)(2 * pl) * band + (uint32_t)t) * (uint32_t)sizeof(OutT);
-                            const uint32_t off_hi = off_lo + band * (uint32_t)sizeof(OutT);
+                            const uint32_t off_lo = (uint32_t)t * (uint32_t)sizeof(OutT), off_hi = off_lo;
+                            OutT *oplane_lo = oplane + (size_t)(2 * pl) * g.bstride, *oplane_hi = oplane_lo + g.bstride;
+                            const size_t hi_delta = g.bstride;
+                            (void)oplane_hi;
                             if (WV_SWT_FASTMID && y0 >= 0 && y0 + TH <= H) {   // interior chunk: all TH rows exist
-                                OutT *orow0 = oplane + (size_t)y0 * W;
+                                OutT *orow0 = oplane_lo + (size_t)y0 * W;
                                 VStep<L, NLEV, TH>::last(cur, tail[pl], taps.lo, taps.hi, [&](int i, float a, float d) {
                                     OutT *orow = orow0 + (size_t)i * W;
                                     store_row(orow, off_lo, (OutT)a);
-                                    store_row(orow, off_hi, (OutT)d);
+                                    store_row(orow + hi_delta, off_hi, (OutT)d);
                                 });
                             } else {
                                 VStep<L, NLEV, TH>::last(cur, tail[pl], taps.lo, taps.hi, [&](int i, float a, float d) {
                                     const int y = y0 + i;
                                     if (y >= 0 && y < H) {
-                                        OutT *orow = oplane + (size_t)y * W;   // uniform: lives in an SGPR pair
+                                        OutT *orow = oplane_lo + (size_t)y * W;   // uniform: lives in an SGPR pair
                                         store_row(orow, off_lo, (OutT)a);
-                                        store_row(orow, off_hi, (OutT)d);
+                                        store_row(orow + hi_delta, off_hi, (OutT)d);
                                     }
                                 });
                             }
@@ -638,10 +647,14 @@ bool swt_slide_covers(int L, int n, int W, int H)
 }
 
 int swt_slide_launch(const void *in, int in_dtype, int in_layout, void *out, int out_dtype, int B, int C, int H,
-                     int W, int n, const float *lo, const float *hi, int L, hipStream_t st)
+                     int W, int n, const float *lo, const float *hi, int L, hipStream_t st, int out_layout,
+                     int64_t band_stride)
 {
     SlideGeom g{};
     g.B = B; g.C = C; g.H = H; g.W = W; g.in_layout = in_layout; g.out_bf16 = out_dtype == WV_DT_BF16;
+    const size_t hw = (size_t)H * W;
+    if (out_layout == WV_BANDS_OUTER) { g.pstride = hw; g.bstride = (size_t)band_stride; }
+    else { g.pstride = 4 * hw; g.bstride = hw; }
 #define WV_CFG(LL, NN) if (L == LL && n == NN) return slide_types<LL, NN, 16, 16, 256, 4>(in, in_dtype, out, g, lo, hi, st)
     WV_CFG(4, 3); WV_CFG(2, 1);
     WV_CFG(4, 1); WV_CFG(4, 2); WV_CFG(2, 2); WV_CFG(2, 3); WV_CFG(8, 1); WV_CFG(10, 1);

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("WVHASH_LIB") or os.path.join(_HERE, "_lib", "libwvhas
 WV_DT_U8, WV_DT_F32, WV_DT_BF16 = 0, 1, 2
 WV_LAYOUT_NCHW, WV_LAYOUT_NHWC = 0, 1
 WV_METRIC_IP, WV_METRIC_L2 = 0, 1
+WV_BANDS_INNER, WV_BANDS_OUTER = 0, 1
 
 
 class WvhashUnavailable(RuntimeError):
@@ -49,7 +50,11 @@ SIGNATURES = {
     "wv_abi_version": (_i, []),
     "wv_swt2d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "wv_swt2d_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _fp, _fp, _i, _vp, _sz, _vp]),
+    "wv_swt2d_forward_ex": (_i, [_vp, _i, _i, _vp, _i, _i, _i64, _i, _i, _i, _i, _i, _fp, _fp, _i, _vp, _sz, _vp]),
     "wv_rawstack_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "wv_swt2d_forward_cpu": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _fp, _fp, _i]),
+    "wv_rawstack_forward_cpu": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i]),
+    "wv_dwt2d_forward_cpu": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _fp, _fp, _i]),
     "wv_dwt_out_len": (_i, [_i, _i, _i]),
     "wv_dwt2d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "wv_dwt2d_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _fp, _fp, _i, _vp, _sz, _vp]),

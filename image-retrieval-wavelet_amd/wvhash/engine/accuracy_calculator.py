@@ -112,7 +112,7 @@ class CustomCalculator(object):
     def calc_hamming_dist(self, qB, rB):
         """0.5 * (B - qB @ rB.T) for +-1 codes (:183-186) -> fp32 [Q, N] like the reference."""
         qB, rB = _to_gpu(qB), _to_gpu(rB)
-        return H.hamming_dist(H.pack_codes(qB), H.pack_codes(rB)).float()
+        return H.hamming_dist(H.pack_codes(qB), H.pack_codes(rB), nbits=qB.shape[1]).float()
 
     def per_bit_balance(self, reference):
         reference = _to_gpu(reference)

@@ -52,10 +52,13 @@ class GlobalEmbeddingSpaceTester:
         _lib.require_gpu()
         s = 0
         all_q = labels = None
+        expand = self._deferred_expander(dataloader.dataset, trunk_model)
         with torch.no_grad():
             LOGGER.info("Computing embeddings")
             for i, data in enumerate(dataloader):
                 img, label = self.data_and_label_getter(data)
+                if expand is not None and img.dim() == 4:
+                    img = expand(img)
                 q = trunk_model(img)
                 if embedder_model is not None:
                     q = embedder_model(q)
@@ -73,6 +76,23 @@ class GlobalEmbeddingSpaceTester:
                 labels[s:e] = label
                 s = e
         return all_q, labels
+
+    @staticmethod
+    def _deferred_expander(dataset, trunk_model):
+        """A dataset whose wavelet plugin was built with defer=True yields raw uint8 [3,H,W] images.  The plugin
+        object itself says how to expand them (class, wavelet, level, copies): bind it to the model when the model
+        can expand on its own (band-major, no second copy), else expand here after the H2D copy."""
+        from ..transforms.custom_transforms import find_wavelet_transform
+        tf = find_wavelet_transform(dataset)
+        if tf is None or not tf.defer:
+            return None
+        inner = getattr(trunk_model, "module", trunk_model)          # nn.DataParallel (evaluate.py:70-71)
+        if hasattr(inner, "bind_transform"):
+            inner.bind_transform(tf)
+            LOGGER.info(f"deferred transform bound to the model: {tf}")
+            return None
+        LOGGER.info(f"deferred transform applied by the engine after the H2D copy: {tf}")
+        return tf.apply_batch
 
     def get_all_embeddings(self, dataset, trunk_model, embedder_model=None):
         dl = DataLoader(dataset, batch_size=self.batch_size, num_workers=self.dataloader_num_workers,
@@ -106,6 +126,8 @@ class GlobalEmbeddingSpaceTester:
         r_emb = torch.cat([embeddings_and_labels[n][0] for n in reference_split_names], dim=0)
         r_lab = torch.cat([embeddings_and_labels[n][1] for n in reference_split_names], dim=0)
         same_source = query_split_name in reference_split_names
+        LOGGER.info("label mode: " + ("whole label matrix (relevance = shares >= 1 tag)" if self.label_hierarchy_level
+                                      is None else f"label column(s) {self.label_hierarchy_level} (PML level slicing)"))
         for level in self._levels(q_lab):
             ql = q_lab if level is None else q_lab[:, level]
             rl = r_lab if level is None else r_lab[:, level]

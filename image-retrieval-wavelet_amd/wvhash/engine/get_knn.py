@@ -4,10 +4,11 @@
 * ``distance_metric in ("hamming", "cosine")``: scores = q @ r.T, top-k largest (get_knn.py:63-66).
   +-1 codes take the bit-packed XOR/popcount kernel; the returned "distances" are the same inner
   products the reference returns (nbits - 2 * hamming).  Anything else takes the fp32 kernel.
-* otherwise: true L2 (torch.cdist semantics, get_knn.py:67-69), top-k smallest.
+* otherwise: L2, top-k smallest.  The reference's two back-ends disagree on the returned VALUES (same order):
+  ``with_faiss=True`` (its default) returns faiss IndexFlatL2's SQUARED distances (get_knn.py:38-39,55),
+  ``with_faiss=False`` returns torch.cdist's true distances (:67-69).  ``with_faiss`` selects the same here.
 Ties are returned in ascending reference index (the reference's order inside a tie is whatever
-torch.topk / faiss produce: implementation-defined).  ``with_faiss`` is accepted and ignored: both of
-the reference's back-ends are replaced by the same HIP kernels.
+torch.topk / faiss produce: implementation-defined).  Both back-ends are the same HIP kernels.
 """
 import ctypes
 import logging
@@ -72,6 +73,8 @@ def get_knn(references, queries, num_k, embeddings_come_from_same_source, with_f
         indices = idx.long()
     else:
         distances, idx = knn_float(references, queries, num_k, _lib.WV_METRIC_L2)
+        if with_faiss:                       # IndexFlatL2.search returns squared L2 (get_knn.py:38-39,55)
+            distances = distances * distances
         indices = idx.long()
 
     if embeddings_come_from_same_source:

@@ -93,15 +93,22 @@ class PreparedDB:
         return self.packed.device
 
 
-def hamming_dist(q_packed, db):
+def hamming_dist(q_packed, db, nbits=None):
     """-> uint8 [Q, N] view (row pitch padded to 64 bytes so every row store is 16-B aligned).
-    `db`: packed int64 codes [N, words] or a PreparedDB."""
+    `db`: packed int64 codes [N, words] or a PreparedDB.  Distances are bytes: codes of more than 255 bits could
+    reach 256 (complementary codes), which would wrap to 0 -- refused; `nbits` tells a 193..255-bit code
+    (4 words, fine) from a 256-bit one."""
     lib = _lib.require_gpu()
     Q, words = q_packed.shape
     prepared = isinstance(db, PreparedDB)
     N, dwords = (db.N, db.words) if prepared else db.shape
     if dwords != words:
         raise ValueError("hamming_dist: query and database code widths differ")
+    if nbits is None:
+        nbits = db.nbits if prepared else words * 64
+    if nbits > 255 or _words(nbits) != words:
+        raise ValueError(f"hamming_dist: uint8 distances need nbits <= 255 matching the packed width "
+                         f"(got nbits={nbits}, {words} words); pass nbits for 193..255-bit codes")
     ld = (N + 63) // 64 * 64
     buf = torch.empty((Q, ld), dtype=torch.uint8, device=q_packed.device)
     if Q and N:

@@ -52,21 +52,48 @@ def _cls(out):
 
 
 class _WaveletHashingBase(nn.Module):
-    """Shared input handling: raw image batches are expanded by the batched HIP SWT."""
+    """Shared input handling.  The reference's models take the expanded ``[B, 3, 4, H, W]`` sub-band tensor
+    (multi_dino_attention.py:815-818, :745); these take that unchanged, and also the raw ``[B, 3, H, W]`` image
+    batch a deferred transform emits -- expanded here by the batched HIP kernel of the transform that was BOUND to
+    the model (``bind_transform``; ``engine.evaluate`` binds ``dataset.transform`` by itself).  A raw batch carries
+    no wavelet name, so without a bound transform a 4-D input is an error, never a default wavelet."""
 
-    swt_level = 1
-    swt_wavelet = "haar"
+    _bound_transform = None
 
-    def set_wavelet(self, level=1, wavelet="haar"):
-        self.swt_level, self.swt_wavelet = level, wavelet
+    def bind_transform(self, transform):
+        """``transform``: the wavelet plugin (or a pipeline / dataset holding one) that produced the raw batches."""
+        from ..transforms.custom_transforms import find_wavelet_transform
+        found = find_wavelet_transform(transform)
+        if found is None:
+            raise ValueError("bind_transform: no SWTTransform / RawStackTransform / DWTTransform in the given pipeline")
+        self._bound_transform = found
         return self
 
-    def _bands(self, x):
-        if x.dim() == 4:                                   # [B, 3, H, W] raw batch (deferred transform)
-            return TF.swt2d(x, self.swt_wavelet, self.swt_level)
-        if x.dim() != 5:
+    def set_wavelet(self, level=1, wavelet="haar"):
+        """Shorthand: raw batches are to be expanded by SWTTransform(level, wavelet)."""
+        from ..transforms import SWTTransform
+        return self.bind_transform(SWTTransform(level=level, wavelet=wavelet, defer=True))
+
+    def _band_major(self, x):
+        """-> [4, B, 3, H, W] (band-major; a view whenever the memory already lies that way)."""
+        if x.dim() == 5:
+            return x.permute(2, 0, 1, 3, 4)
+        if x.dim() != 4:
             raise ValueError(f"expected [B,3,4,H,W] sub-bands or a [B,3,H,W] image batch, got {tuple(x.shape)}")
-        return x
+        tf = self._bound_transform
+        if tf is None:
+            raise RuntimeError(
+                "this model received a raw [B,3,H,W] image batch (a deferred transform's output) but no transform "
+                "is bound to it: call model.bind_transform(dataset.transform) (wvhash.engine.evaluate does) or "
+                "model.set_wavelet(level, wavelet); the wavelet is never guessed")
+        from ..transforms import SWTTransform
+        if isinstance(tf, SWTTransform):
+            # written band-major by the kernel: the band split below is a view, the sub-bands exist once in HBM.
+            # Under bf16 autocast the backbone's first op casts its input to bf16 anyway: emit bf16 directly.
+            bf16 = torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+            return TF.swt2d(x, tf.wavelet, tf.level, band_major=True,
+                            out_dtype=torch.bfloat16 if bf16 else torch.float32)
+        return tf.apply_batch(x).permute(2, 0, 1, 3, 4)
 
     def _tail(self, fused_embedding):
         if not self.training and fused_embedding.is_cuda and not torch.is_grad_enabled():
@@ -100,10 +127,10 @@ class SharedDinoHashing(_WaveletHashingBase):
         return torch.tanh(logits)
 
     def fused_embedding(self, x):
-        x = self._bands(x)
-        b, c, s, h, w = x.shape
-        x_concat = x.permute(2, 0, 1, 3, 4).contiguous().view(b * s, c, h, w)
-        cls_tokens = _cls(self.shared_backbone(x_concat))
+        bands = self._band_major(x)                      # [4, B, 3, H, W]
+        s, b, c, h, w = bands.shape
+        x_concat = bands.reshape(s * b, c, h, w)         # a view for kernel-written bands; the reference's copy
+        cls_tokens = _cls(self.shared_backbone(x_concat))  # (multi_dino_attention.py:818) for a 5-D input
         return self.fusion_head(list(cls_tokens.chunk(4, dim=0)))
 
     def forward(self, x):
@@ -137,8 +164,8 @@ class MultiDinoHashing(_WaveletHashingBase):
         return logits
 
     def fused_embedding(self, x):
-        x = self._bands(x)
-        features = [_cls(backbone(x[..., i, :, :])) for i, backbone in enumerate(self.backbones)]
+        bands = self._band_major(x)                      # bands[i] = x[..., i, :, :] (:745)
+        features = [_cls(backbone(bands[i])) for i, backbone in enumerate(self.backbones)]
         return self.fusion_head(features)
 
     def forward(self, x):

@@ -63,7 +63,8 @@ def _all_reduce(t, op, group):
         dist.all_reduce(t, op=op, group=group)
 
 
-def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, workspace=None, trim=True):
+def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, workspace=None, trim=True,
+                         send_hint=None, return_need=False):
     """q_local: packed codes of THIS rank's queries [Ql, words]; db_shard: this rank's rows
     [lo:hi] of the packed database (tensor or PreparedDB).  Returns the global (idx int32 [Ql,k], dist uint8
     [Ql,k]) of the local queries.  Every rank must call with the same Ql.
@@ -72,10 +73,16 @@ def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, works
     of it (Q*(nbits+2)*4 bytes) gives every rank the global k-th distance T of every query, a shard then only
     has to send its list prefix with distance <= T.  The prefix length used is the maximum over all queries
     and shards (one scalar MAX all-reduce + one host read), so the exchange stays a fixed-size all_to_all --
-    typically ~k/world + ties entries per query instead of min(k, shard rows)."""
+    typically ~k/world + ties entries per query instead of min(k, shard rows).
+
+    send_hint (with trim): prefix length to exchange WITHOUT the host read -- for a steady stream of query batches
+    (serving, bench.py) whose needed length is known from earlier batches.  The call then never synchronises with the
+    host; the result is exact iff the returned `need` (device int32 [1], return_need=True) is <= send_hint, which
+    the caller checks whenever it next synchronises anyway (`exchange_ok`)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
-        return H.hamming_topk(q_local, db_shard, nbits, k, workspace=workspace)
+        out = H.hamming_topk(q_local, db_shard, nbits, k, workspace=workspace)
+        return (out[0], out[1], None) if return_need else out
     rank = dist.get_rank(group)
     Ql, words = q_local.shape
     lo, hi, per = shard_bounds(n_total, world, rank)
@@ -98,6 +105,7 @@ def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, works
         else:
             i, d = H.hamming_topk(q_all, db_shard, nbits, k_local, idx_offset=lo, workspace=workspace)
     send = kin
+    need = None
     if trim:
         if cum is None:                                 # empty shard: contributes nothing
             cum = torch.zeros((world * Ql, nbits + 2), dtype=torch.int32, device=dev)
@@ -107,7 +115,10 @@ def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, works
         T = (cum_g[:, 1:] >= k).int().argmax(dim=1)
         need = torch.gather(cum, 1, (T + 1).unsqueeze(1).long()).max().reshape(1)   # local rows with distance <= T
         _all_reduce(need, dist.ReduceOp.MAX, group)
-        send = max(1, min(kin, int(need.item())))       # the one host read of the exchange
+        if send_hint is None:
+            send = max(1, min(kin, int(need.item())))   # exact sizing: the one host read of the exchange
+        else:
+            send = max(1, min(kin, int(send_hint)))     # no host read; the caller verifies need <= send_hint
     if trim and per <= 65536:
         # compact exchange: 16-bit LOCAL row numbers (2 bytes/entry) and, instead of a distance row, the shard's
         # cumulative histogram of each query (a sorted list is fully described by it): 2 bytes per entry + 4*(nbits+2)
@@ -122,7 +133,8 @@ def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, works
         cum_r = torch.empty_like(cum)
         _all_to_all(cum_r, cum.contiguous(), group)
         # received layout: [shard g][my Ql queries][...]
-        return H.topk_merge_cum(loc_r.view(world, Ql, send), cum_r.view(world, Ql, nbits + 2), per, k, nbits)
+        out = H.topk_merge_cum(loc_r.view(world, Ql, send), cum_r.view(world, Ql, nbits + 2), per, k, nbits)
+        return (out[0], out[1], need) if return_need else out
     idx_s = torch.full((world * Ql, send), -1, dtype=torch.int32, device=dev)
     dist_s = torch.full((world * Ql, send), pad_value(nbits), dtype=torch.uint8, device=dev)
     if k_local > 0:
@@ -134,4 +146,15 @@ def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, works
     _all_to_all(idx_r, idx_s, group)
     _all_to_all(dist_r, dist_s, group)
     # received layout: [shard g][my Ql queries][send]  ->  merge
-    return H.topk_merge(idx_r.view(world, Ql, send), dist_r.view(world, Ql, send), k, nbits)
+    out = H.topk_merge(idx_r.view(world, Ql, send), dist_r.view(world, Ql, send), k, nbits)
+    return (out[0], out[1], need) if return_need else out
+
+
+def exchange_ok(needs, send_hint, kin):
+    """True when every `need` a hinted call returned fits the prefix length that was exchanged (one host read for
+    the whole list; call it where the host synchronises anyway)."""
+    needs = [n for n in needs if n is not None]
+    if not needs:
+        return True
+    worst = int(torch.stack([n.reshape(()) for n in needs]).max().item())
+    return worst <= max(1, min(int(kin), int(send_hint)))

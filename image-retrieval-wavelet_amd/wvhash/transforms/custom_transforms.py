@@ -1,14 +1,19 @@
 """Drop-in wavelet transform plugins: same class names, kwargs, output layout and repr as
-/root/reference/main/transforms/custom_transforms.py:126-205, computed by the HIP kernels.
+/root/reference/main/transforms/custom_transforms.py:126-205.
 
-Two ways to use them
-* per image, exactly like the reference: ``SWTTransform(level, wavelet)(pil_img)`` ->
-  ``FloatTensor[3, 4, H', W']`` (computed on the GPU; the call must run in a process that owns
-  the device, i.e. ``num_workers=0``);
-* batched (how the path is meant to run): construct with ``defer=True``; inside DataLoader
-  workers the transform then only sizes the image and returns the raw ``uint8 [3, H', W']``
-  tensor (no GPU touched in the worker), and ``transform.apply_batch(batch_u8_on_gpu)`` -- called
-  by the evaluation engine / the model wrapper after collate -- runs the one batched kernel.
+Where ``SWTTransform(level, wavelet)(pil_img)`` computes (the result is always ``FloatTensor[3, 4, H', W']``):
+* inside a DataLoader worker process (``torch.utils.data.get_worker_info()`` is set) -- the way the reference's
+  unchanged YAML + ``DataLoader(num_workers > 0)`` calls it (flikr_coco.py:59-60) -- or with ``device="cpu"``:
+  the library's host twin ``wv_swt2d_forward_cpu`` (single-threaded native code, no HIP call, fork-safe); a forked
+  worker cannot use the parent's GPU context;
+* in a process that owns the device: the HIP kernel (one image per call);
+* no GPU and no ``device="cpu"``: ``WvhashUnavailable`` -- the transform never silently changes device.
+The fast way to run the path is batched: construct with ``defer=True`` (``build_transform(cfg, defer=True)``); the
+workers then only size the image and return the raw ``uint8 [3, H', W']`` tensor (16x fewer bytes over PCIe than
+the expanded fp32 sub-bands), and the evaluation engine / the model run ``transform.apply_batch`` on the GPU after
+collate.  A deferred batch carries no wavelet name: ``engine.evaluate`` reads it from ``dataset.transform`` and binds
+the transform to the model (``model.bind_transform``); a model that receives a raw 4-D batch without a bound
+transform raises instead of guessing.
 """
 import numpy as np
 import torch
@@ -48,9 +53,17 @@ class BaseWaveletTransform(object):
     def _device(self):
         return torch.device(self.device) if self.device is not None else torch.device("cuda", torch.cuda.current_device())
 
-    def apply_batch(self, batch, channels_last=False):
-        """Batched device path.  batch: uint8/float32 [B,3,H,W] (or [B,H,W,3]) on the GPU."""
+    def apply_batch(self, batch, channels_last=False, **kwargs):
+        """Batched path.  batch: uint8/float32 [B,3,H,W] (or [B,H,W,3]); GPU tensors take the HIP kernel, host
+        tensors the host twin."""
         raise NotImplementedError
+
+    def _use_host(self):
+        """True when __call__ must not touch the GPU: explicit device='cpu', or a DataLoader worker process."""
+        if self.device is not None and torch.device(self.device).type == "cpu":
+            return True
+        from torch.utils.data import get_worker_info
+        return get_worker_info() is not None
 
     def __call__(self, img):
         arr = self._to_u8_hwc(img)
@@ -58,21 +71,54 @@ class BaseWaveletTransform(object):
             if arr.dtype != np.uint8:
                 raise TypeError("deferred transforms expect 8-bit images")
             return torch.from_numpy(arr).permute(2, 0, 1).contiguous()
-        from .. import _lib
-        _lib.require_gpu()
         if arr.dtype == np.uint8:
             x = torch.from_numpy(arr)
         else:  # the reference computes astype(float32) / 255 for any dtype
             x = torch.from_numpy(arr.astype(np.float32) / 255.0)
-        x = x.unsqueeze(0).to(self._device(), non_blocking=True)
-        return self.apply_batch(x, channels_last=True)[0].cpu().float()
+        x = x.unsqueeze(0)
+        if self._use_host():
+            return self.apply_batch(x, channels_last=True)[0]
+        from .. import _lib
+        try:
+            _lib.require_gpu()
+        except _lib.WvhashUnavailable as e:
+            raise _lib.WvhashUnavailable(f"{e}; pass device='cpu' to run the library's host twin in this process "
+                                         "(DataLoader workers take it automatically)") from None
+        return self.apply_batch(x.to(self._device(), non_blocking=True), channels_last=True)[0].cpu().float()
+
+    def deferred_spec(self):
+        """What a deferred batch needs to be expanded later: (kind, wavelet, level, copies)."""
+        return (type(self).__name__, self.wavelet, self.level, getattr(self, "copies", 4))
+
+
+def find_wavelet_transform(obj):
+    """The wavelet plugin inside a transform pipeline (a plugin itself, a Compose-like object with a
+    ``transforms`` list, or a dataset with a ``transform`` attribute); None when there is none."""
+    if isinstance(obj, BaseWaveletTransform):
+        return obj
+    for attr in ("transform", "transforms"):
+        inner = getattr(obj, attr, None)
+        if inner is None:
+            continue
+        if isinstance(inner, (list, tuple)):
+            for t in inner:
+                found = find_wavelet_transform(t)
+                if found is not None:
+                    return found
+        else:
+            found = find_wavelet_transform(inner)
+            if found is not None:
+                return found
+    return None
 
 
 class SWTTransform(BaseWaveletTransform):
     """Stationary wavelet transform (size preserved: H, W)."""
 
-    def apply_batch(self, batch, channels_last=False):
-        return F.swt2d(batch, self.wavelet, self.level, channels_last=channels_last)
+    def apply_batch(self, batch, channels_last=False, **kwargs):
+        if not batch.is_cuda:
+            return F.swt2d_host(batch, self.wavelet, self.level, channels_last=channels_last)
+        return F.swt2d(batch, self.wavelet, self.level, channels_last=channels_last, **kwargs)
 
     def __repr__(self):
         return f"SWTTransform(shape='C,S,H,W', wavelet={self.wavelet}, level={self.level})"
@@ -85,7 +131,9 @@ class RawStackTransform(BaseWaveletTransform):
         super().__init__(level=level, wavelet=wavelet, defer=defer, device=device)
         self.copies = copies
 
-    def apply_batch(self, batch, channels_last=False):
+    def apply_batch(self, batch, channels_last=False, **kwargs):
+        if not batch.is_cuda:
+            return F.rawstack_host(batch, self.copies, channels_last=channels_last)
         return F.rawstack(batch, self.copies, channels_last=channels_last)
 
     def __repr__(self):
@@ -100,7 +148,9 @@ class DWTTransform(BaseWaveletTransform):
     def __init__(self, level=1, wavelet='haar', defer=False, device=None):
         super().__init__(level=level, wavelet=wavelet, defer=defer, device=device)
 
-    def apply_batch(self, batch, channels_last=False):
+    def apply_batch(self, batch, channels_last=False, **kwargs):
+        if not batch.is_cuda:
+            return F.dwt2d_host(batch, self.wavelet, self.level, channels_last=channels_last)
         return F.dwt2d(batch, self.wavelet, self.level, channels_last=channels_last)
 
     def __repr__(self):

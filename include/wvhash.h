@@ -62,10 +62,40 @@ int wv_swt2d_forward(const void *in, int in_dtype, int in_layout, void *out, int
                      int C, int H, int W, int level, const float *dec_lo, const float *dec_hi,
                      int flen, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Same transform with a choice of output layout.
+ *   WV_BANDS_INNER: out [B][C][4][H][W] -- the reference's tensor (custom_transforms.py:155-157, batched).
+ *   WV_BANDS_OUTER: out [4][B'][C][H][W], band_stride = B'*C*H*W elements between the bands of one plane
+ *                   (B' >= B: a chunk of a larger batch may be written in place).  Every band is then one
+ *                   contiguous NCHW batch: exactly what SharedDinoHashing.forward builds with
+ *                   x.permute(2,0,1,3,4).contiguous().view(4B,3,H,W) (multi_dino_attention.py:818) and what
+ *                   MultiDinoHashing indexes per backbone (:745) -- written directly, without that second copy of
+ *                   the sub-band tensor.  Returns WV_ENOTSUP for shapes only the tiled/generic kernels cover. */
+#define WV_BANDS_INNER 0
+#define WV_BANDS_OUTER 1
+int wv_swt2d_forward_ex(const void *in, int in_dtype, int in_layout, void *out, int out_dtype, int out_layout,
+                        int64_t band_stride, int B, int C, int H, int W, int level, const float *dec_lo,
+                        const float *dec_hi, int flen, void *workspace, size_t workspace_bytes, void *stream);
+
 /* RawStackTransform (custom_transforms.py:172-188): `copies` identical planes per channel.
  * out: [B][C][copies][H][W]. */
 int wv_rawstack_forward(const void *in, int in_dtype, int in_layout, void *out, int out_dtype,
                         int B, int C, int H, int W, int copies, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Host twins of the three transform entry points ("_cpu twins taking host pointers").
+ * The reference calls its transform inside forked DataLoader worker processes, one image at a time
+ *   (main/datasets/flikr_coco.py:59-60 -> custom_transforms.py:145-157); a forked worker cannot use the parent's
+ *   GPU context, so with an unchanged transform YAML and num_workers > 0 the plugin's __call__ runs these.
+ * in / out are HOST pointers; out is float32 [B][C][4|copies][H'][W'] like the device entry points.
+ * No HIP call, no thread started, no global state: safe after fork().  Float32 arithmetic in the order of the
+ * device kernels (bit-identical to wv_swt2d_forward on the shapes its sliding kernel covers).
+ * ------------------------------------------------------------------------------------------ */
+int wv_swt2d_forward_cpu(const void *in, int in_dtype, int in_layout, float *out, int B, int C, int H, int W,
+                         int level, const float *dec_lo, const float *dec_hi, int flen);
+int wv_rawstack_forward_cpu(const void *in, int in_dtype, int in_layout, float *out, int B, int C, int H, int W,
+                            int copies);
+int wv_dwt2d_forward_cpu(const void *in, int in_dtype, int in_layout, float *out, int B, int C, int H, int W,
+                         int level, const float *dec_lo, const float *dec_hi, int flen);
 
 /* Decimated multi-level 2-D DWT (DWTTransform, custom_transforms.py:191-205 -> pywt.wavedec2, mode
  * 'symmetric'): the four bands (cA, cH, cV, cD) of the coarsest level.

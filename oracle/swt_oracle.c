@@ -35,21 +35,57 @@
 
 /* built with -ffp-contract=off (oracle/Makefile): products round before the add */
 
-/* One periodized a-trous pass along a strided 1-D signal (PyWavelets
- * downsampling_convolution_periodization with step = 1, fstep = s). */
-static void atrous_1d(const float *x, ptrdiff_t xstride, int n, const float *f, int L, int s,
-                      float *y, ptrdiff_t ystride)
+/* One periodized a-trous pass (PyWavelets downsampling_convolution_periodization with step = 1, fstep = s) over a
+ * whole H x W plane along `axis`: every output element is   sum = 0; for m = 0..L-1: sum = sum + f[m] * x[idx_m]
+ * with idx_m = (o + s*(L/2 - m)) mod N -- products rounded before the add, taps in order.  The loops run tap-outer /
+ * element-inner over whole rows (each element still sees exactly that sequence of operations), which the compiler can
+ * vectorise: the CPU baseline should not be slower than a careful C library would be. */
+static long wrap_index(long idx, int n)
 {
-    for (int o = 0; o < n; ++o) {
-        float sum = 0.0f;
-        for (int m = 0; m < L; ++m) {
-            long idx = (long)o + (long)s * (L / 2 - m);
-            idx %= n;
-            if (idx < 0) idx += n;
-            float prod = f[m] * x[idx * xstride];
-            sum = sum + prod;
+    idx %= n;
+    return idx < 0 ? idx + n : idx;
+}
+
+static void atrous_plane(const float *A, int H, int W, const float *f, int L, int s, int axis, float *Y, float *pad)
+{
+    if (axis == 0) {
+        for (int y = 0; y < H; ++y) {
+            float *out = Y + (size_t)y * W;
+            for (int x = 0; x < W; ++x) out[x] = 0.0f;
+            for (int m = 0; m < L; ++m) {
+                const float *src = A + (size_t)wrap_index((long)y + (long)s * (L / 2 - m), H) * W;
+                const float fm = f[m];
+                for (int x = 0; x < W; ++x) {
+                    float prod = fm * src[x];
+                    out[x] = out[x] + prod;
+                }
+            }
         }
-        y[o * ystride] = sum;
+        return;
+    }
+    /* axis 1: left / right periodic margins so that the inner loop reads a contiguous window */
+    long dmin = 0, dmax = 0;
+    for (int m = 0; m < L; ++m) {
+        long d = (long)s * (L / 2 - m);
+        if (d < dmin) dmin = d;
+        if (d > dmax) dmax = d;
+    }
+    const long left = -dmin, right = dmax;
+    for (int y = 0; y < H; ++y) {
+        const float *row = A + (size_t)y * W;
+        for (long i = 0; i < left; ++i) pad[i] = row[wrap_index(i - left, W)];
+        memcpy(pad + left, row, (size_t)W * sizeof(float));
+        for (long i = 0; i < right; ++i) pad[left + W + i] = row[wrap_index(i, W)];
+        float *out = Y + (size_t)y * W;
+        for (int x = 0; x < W; ++x) out[x] = 0.0f;
+        for (int m = 0; m < L; ++m) {
+            const float *src = pad + left + (long)s * (L / 2 - m);
+            const float fm = f[m];
+            for (int x = 0; x < W; ++x) {
+                float prod = fm * src[x];
+                out[x] = out[x] + prod;
+            }
+        }
     }
 }
 
@@ -58,20 +94,14 @@ static void atrous_1d(const float *x, ptrdiff_t xstride, int n, const float *f, 
  * Band keys: first letter = axis 0.  aa = cA, da = cH, ad = cV, dd = cD. */
 static void swt2_level(const float *A, int H, int W, const float *lo, const float *hi, int L,
                        int s, float *aa, float *da, float *ad, float *dd, float *tmp_a,
-                       float *tmp_d)
+                       float *tmp_d, float *pad)
 {
-    /* axis 0: filter down each column */
-    for (int x = 0; x < W; ++x) {
-        atrous_1d(A + x, W, H, lo, L, s, tmp_a + x, W);
-        atrous_1d(A + x, W, H, hi, L, s, tmp_d + x, W);
-    }
-    /* axis 1: filter along each row */
-    for (int y = 0; y < H; ++y) {
-        atrous_1d(tmp_a + (size_t)y * W, 1, W, lo, L, s, aa + (size_t)y * W, 1);
-        atrous_1d(tmp_a + (size_t)y * W, 1, W, hi, L, s, ad + (size_t)y * W, 1);
-        atrous_1d(tmp_d + (size_t)y * W, 1, W, lo, L, s, da + (size_t)y * W, 1);
-        atrous_1d(tmp_d + (size_t)y * W, 1, W, hi, L, s, dd + (size_t)y * W, 1);
-    }
+    atrous_plane(A, H, W, lo, L, s, 0, tmp_a, pad);
+    atrous_plane(A, H, W, hi, L, s, 0, tmp_d, pad);
+    atrous_plane(tmp_a, H, W, lo, L, s, 1, aa, pad);
+    atrous_plane(tmp_a, H, W, hi, L, s, 1, ad, pad);
+    atrous_plane(tmp_d, H, W, lo, L, s, 1, da, pad);
+    atrous_plane(tmp_d, H, W, hi, L, s, 1, dd, pad);
 }
 
 /* pywt.swt2(plane, wavelet, level)[0] -> out[4][H][W] = (cA, cH, cV, cD) of level `level`.
@@ -88,17 +118,18 @@ int wvo_swt2_plane_f32(const float *plane, int H, int W, const float *dec_lo, co
     float *cur = (float *)malloc(n * sizeof(float));
     float *ta = (float *)malloc(n * sizeof(float));
     float *td = (float *)malloc(n * sizeof(float));
-    if (!cur || !ta || !td) {
-        free(cur); free(ta); free(td);
+    float *pad = (float *)malloc(((size_t)W + 2 * (size_t)L * ((size_t)1 << (level - 1)) + 8) * sizeof(float));
+    if (!cur || !ta || !td || !pad) {
+        free(cur); free(ta); free(td); free(pad);
         return -2;
     }
     memcpy(cur, plane, n * sizeof(float));
     float *aa = out, *da = out + n, *ad = out + 2 * n, *dd = out + 3 * n;
     for (int l = 1; l <= level; ++l) {
-        swt2_level(cur, H, W, dec_lo, dec_hi, L, 1 << (l - 1), aa, da, ad, dd, ta, td);
+        swt2_level(cur, H, W, dec_lo, dec_hi, L, 1 << (l - 1), aa, da, ad, dd, ta, td, pad);
         if (l < level) memcpy(cur, aa, n * sizeof(float));
     }
-    free(cur); free(ta); free(td);
+    free(cur); free(ta); free(td); free(pad);
     return 0;
 }
 

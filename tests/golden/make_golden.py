@@ -8,8 +8,16 @@ What each file pins
   sibling hub_utils.py; nothing else of the reference is importable here) on seeded inputs and
   seeded weights (wvhash.synth.head_state; only the seed and a SHA of the weights are stored).
   This is the only piece of the hot path whose reference code runs in this image.
-* ranking_golden.npz -- outputs of oracle/ranking.py (stock torch CPU ops, the same calls the
-  reference makes at accuracy_calculator.py:183-231 and get_knn.py:60-71).
+* ranking_golden.npz -- outputs of the REFERENCE's own ranking code, executed here: the modules
+  accuracy_calculator.py / get_knn.py cannot be imported (pytorch_metric_learning, torchmetrics, faiss are
+  absent: ordinary ModuleNotFoundError), but the bodies of label_comparison_fn, calc_hamming_dist,
+  per_bit_balance, calculate_bit_balance, calculate_worst_bit_balance, calculate_maphashing
+  (accuracy_calculator.py:31-37, 183-231) and get_knn / get_knn_torch (get_knn.py:9-24, 60-71) use only torch.
+  They are cut out of the reference files with `ast` at generation time (nothing of the source is stored),
+  compiled unmodified and run on seeded inputs; a recording proxy around `torch.argsort` captures the order the
+  reference's literal (unstable) call produced.  Keys `<case>/ref_*` hold those outputs; the canonical (stable)
+  lists next to them come from oracle/ranking.py and are checked here against the reference's order (same
+  sorted distances, same index set per complete distance bucket).
 * swt_golden.npz     -- outputs of oracle/swt_oracle.c (PyWavelets is absent: these pin the
   restatement against regressions and carry the analytic known answers, not pywt output).
 
@@ -105,54 +113,168 @@ def make_head_golden():
 
 
 # --------------------------------------------------------------------------------- ranking
+def _cut(path, class_name, names):
+    """FunctionDef nodes `names` of `class_name` (or module level when class_name is None), unmodified."""
+    import ast
+    with open(path, "r") as f:
+        tree = ast.parse(f.read(), filename=path)
+    body = tree.body
+    if class_name is not None:
+        body = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == class_name).body
+    found = {n.name: n for n in body if isinstance(n, ast.FunctionDef) and n.name in names}
+    missing = [n for n in names if n not in found]
+    if missing:
+        raise RuntimeError(f"{path}: {missing} not found")
+    return [found[n] for n in names]
+
+
+class _TorchProxy(types.ModuleType):
+    """`torch` as the reference's functions see it: everything delegates, argsort calls are recorded."""
+
+    def __init__(self):
+        super().__init__("torch")
+        self.argsort_log = []
+
+    def __getattr__(self, name):
+        return getattr(torch, name)
+
+    def argsort(self, *args, **kwargs):
+        out = torch.argsort(*args, **kwargs)
+        self.argsort_log.append(out.clone())
+        return out
+
+
+def load_reference_ranking():
+    """-> (calculator instance running the reference's CustomCalculator methods, get_knn function, torch proxy)."""
+    import ast
+    import logging
+    proxy = _TorchProxy()
+    methods = _cut(os.path.join(REF, "main", "engine", "accuracy_calculator.py"), "CustomCalculator",
+                   ["label_comparison_fn", "calc_hamming_dist", "per_bit_balance", "calculate_bit_balance",
+                    "calculate_worst_bit_balance", "calculate_maphashing"])
+    cls = ast.ClassDef(name="RefCalculator", bases=[], keywords=[], body=methods, decorator_list=[])
+    mod = ast.Module(body=[cls], type_ignores=[])
+    ast.fix_missing_locations(mod)
+    ns = {"torch": proxy}
+    exec(compile(mod, "<reference accuracy_calculator.py (cut)>", "exec"), ns)
+    calc = ns["RefCalculator"]()
+    funcs = _cut(os.path.join(REF, "main", "engine", "get_knn.py"), None, ["get_knn", "get_knn_torch"])
+    mod = ast.Module(body=funcs, type_ignores=[])
+    ast.fix_missing_locations(mod)
+    ns2 = {"torch": torch, "lib": types.SimpleNamespace(LOGGER=logging.getLogger("reference"))}
+    exec(compile(mod, "<reference get_knn.py (cut)>", "exec"), ns2)
+    return calc, ns2["get_knn"], proxy
+
+
 RANK_CASES = [
-    # name, Q, N, nbits, Lc, p, k, structured
-    ("rand_q16_n500_b32", 16, 500, 32, 20, 0.07, 100, False),
-    ("struct_q12_n1000_b64", 12, 1000, 64, 38, 0.10, 300, True),
-    ("struct_q8_n777_b128", 8, 777, 128, 80, 0.036, 777, True),
-    ("rand_q5_n64_b16", 5, 64, 16, 20, 0.07, 10, False),
+    # name, Q, N, nbits, Lc, p, k, kind
+    ("rand_q16_n500_b32", 16, 500, 32, 20, 0.07, 100, "random"),
+    ("struct_q12_n1000_b64", 12, 1000, 64, 38, 0.10, 300, "structured"),
+    ("struct_q8_n777_b128", 8, 777, 128, 80, 0.036, 777, "structured"),
+    ("rand_q5_n64_b16", 5, 64, 16, 20, 0.07, 10, "random"),
+    # every (query, row) distance distinct per query -> the ranking is unique and the reference's unstable argsort
+    # IS the canonical order: mAP and lists must then agree exactly, not only up to tie noise
+    ("tiefree_q8_n60_b128", 8, 60, 128, 38, 0.15, 25, "tiefree"),
 ]
 
 
+def tiefree_codes(Q, N, B, seed):
+    """d(q_i, r_j) = i + pos(j): rows flip a prefix of distinct length (shuffled), queries flip a disjoint suffix."""
+    g = torch.Generator().manual_seed(seed)
+    base = torch.randint(0, 2, (B,), generator=g).float() * 2 - 1
+    perm = torch.randperm(N, generator=g)
+    r = base.repeat(N, 1)
+    for j in range(N):
+        r[j, :int(perm[j])] *= -1
+    q = base.repeat(Q, 1)
+    for i in range(Q):
+        if i:
+            q[i, B - i:] *= -1
+    assert N + Q <= B
+    return q, r
+
+
 def make_ranking_golden():
+    calc, ref_get_knn, proxy = load_reference_ranking()
     out = {}
-    for name, Q, N, B, Lc, p, k, structured in RANK_CASES:
+    for name, Q, N, B, Lc, p, k, kind in RANK_CASES:
         seed = int(hashlib.sha256(name.encode()).hexdigest()[:6], 16)
         ql = ranking.make_labels(Q, Lc, p, seed)
         rl = ranking.make_labels(N, Lc, p, seed + 1)
-        if structured:
+        if kind == "structured":
             q = ranking.make_structured_codes(ql, B, seed + 2, seed + 3)
             r = ranking.make_structured_codes(rl, B, seed + 2, seed + 4)
+        elif kind == "tiefree":
+            q, r = tiefree_codes(Q, N, B, seed)
         else:
             q, r = ranking.make_codes(Q, N, B, seed)
-        d = torch.cat([ranking.calc_hamming_dist(q[i:i + 1], r) for i in range(Q)])
+        # ---- the reference's own code -------------------------------------------------------------------
+        ref_d = torch.cat([calc.calc_hamming_dist(q[i:i + 1], r) for i in range(Q)])          # :183-186
+        ref_gnd = calc.label_comparison_fn(ql, rl)                                            # :31-37
+        proxy.argsort_log.clear()
+        ref_map = calc.calculate_maphashing(q, ql, r, rl, k)                                  # :203-231
+        ref_order = torch.stack(proxy.argsort_log)                                            # its argsort, per query
+        ref_map_all = calc.calculate_maphashing(q, ql, r, rl, None)
+        ref_bb = [calc.calculate_bit_balance(r), calc.calculate_worst_bit_balance(r)]         # :188-200
+        kk = min(k, 50)
+        ref_knn_i, ref_knn_d = ref_get_knn(r, q, kk, False, with_faiss=False, distance_metric="hamming")
+        ref_self_i, ref_self_d = ref_get_knn(r, r[:Q], kk, True, with_faiss=False, distance_metric="hamming")
+        # ---- canonical forms (oracle), checked against the reference's order -------------------------------
+        assert torch.equal(ranking.calc_hamming_dist(q, r), ref_d)
+        assert torch.equal(ranking.label_comparison_fn(ql, rl), ref_gnd)
         idx, dk = ranking.hamming_topk_stable(q, r, k)
-        m_ref, ap_ref = ranking.calculate_maphashing(q, ql, r, rl, k, stable=False, return_per_query=True)
+        di = ref_d.round().long()
+        for i in range(Q):
+            un = ref_order[i][:k]
+            assert torch.equal(di[i][un], dk[i]), name
+            assert ranking.bucket_sets(un, di[i][un]) == ranking.bucket_sets(idx[i], dk[i]), name
         m_st, ap_st = ranking.calculate_maphashing(q, ql, r, rl, k, stable=True, return_per_query=True)
-        knn_d, knn_i = ranking.get_knn_torch(r, q, min(k, 50), "hamming")
+        m_un, ap_un = ranking.calculate_maphashing(q, ql, r, rl, k, stable=False, return_per_query=True)
+        assert m_un == ref_map, (name, m_un, ref_map)        # the restatement runs the same ops: same number
+        if kind == "tiefree":
+            assert torch.equal(ref_order[:, :k], idx) and m_st == ref_map
         out.update({
             f"{name}/q": q.numpy().astype(np.int8), f"{name}/r": r.numpy().astype(np.int8),
             f"{name}/ql": ql.numpy().astype(np.uint8), f"{name}/rl": rl.numpy().astype(np.uint8),
             f"{name}/k": np.array([k]),
-            f"{name}/dist": d.numpy().astype(np.float32),
+            f"{name}/ref_dist": ref_d.numpy().astype(np.float32),
+            f"{name}/ref_gnd": ref_gnd.numpy(),
+            f"{name}/ref_argsort": ref_order.numpy().astype(np.int32),
+            f"{name}/ref_map": np.array([ref_map]), f"{name}/ref_map_all": np.array([ref_map_all]),
+            f"{name}/ref_bit_balance": np.array(ref_bb),
+            f"{name}/ref_knn_idx": ref_knn_i.numpy().astype(np.int32), f"{name}/ref_knn_ip": ref_knn_d.numpy(),
+            f"{name}/ref_selfknn_idx": ref_self_i.numpy().astype(np.int32),
+            f"{name}/ref_selfknn_ip": ref_self_d.numpy(),
+            # names read by the round-1 tests (same numbers as the ref_* keys where both exist)
+            f"{name}/dist": ref_d.numpy().astype(np.float32),
             f"{name}/topk_idx": idx.numpy().astype(np.int32),
             f"{name}/topk_dist": dk.numpy().astype(np.uint8),
             f"{name}/ap_stable": np.array(ap_st, dtype=np.float64),
-            f"{name}/ap_ref": np.array(ap_ref, dtype=np.float64),
-            f"{name}/map_stable": np.array([m_st]), f"{name}/map_ref": np.array([m_ref]),
-            f"{name}/bit_balance": np.array([ranking.calculate_bit_balance(r),
-                                             ranking.calculate_worst_bit_balance(r)]),
-            f"{name}/knn_ip": knn_d.numpy(), f"{name}/knn_idx_ref": knn_i.numpy().astype(np.int32),
+            f"{name}/ap_ref": np.array(ap_un, dtype=np.float64),
+            f"{name}/map_stable": np.array([m_st]), f"{name}/map_ref": np.array([ref_map]),
+            f"{name}/bit_balance": np.array(ref_bb),
+            f"{name}/knn_ip": ref_knn_d.numpy(), f"{name}/knn_idx_ref": ref_knn_i.numpy().astype(np.int32),
         })
-        print(f"rank {name}: mAP stable {m_st:.6f} ref(unstable) {m_ref:.6f}")
-    # float embeddings for the l2 / cosine k-NN entry points (get_knn.py:60-71)
+        print(f"rank {name}: reference mAP@{k} {ref_map:.6f} (canonical {m_st:.6f}), mAP@all {ref_map_all:.6f}")
+    # 1-D class-id labels and mixed-rank labels: the other two branches of label_comparison_fn (:31-37)
+    g = torch.Generator().manual_seed(5)
+    ql1, rl1 = torch.randint(0, 7, (9,), generator=g), torch.randint(0, 7, (120,), generator=g)
+    q1, r1 = ranking.make_codes(9, 120, 32, 6)
+    out["classid/q"], out["classid/r"] = q1.numpy().astype(np.int8), r1.numpy().astype(np.int8)
+    out["classid/ql"], out["classid/rl"] = ql1.numpy(), rl1.numpy()
+    out["classid/ref_gnd"] = calc.label_comparison_fn(ql1, rl1).numpy()
+    ql3 = ranking.make_labels(9, 12, 0.2, 8)
+    knn_lab = ranking.make_labels(9 * 5, 12, 0.2, 9).view(9, 5, 12)
+    out["mixed/ql"], out["mixed/knn_labels"] = ql3.numpy().astype(np.uint8), knn_lab.numpy().astype(np.uint8)
+    out["mixed/ref_gnd"] = calc.label_comparison_fn(ql3[:, None], knn_lab).numpy()
+    # float embeddings for the l2 / cosine k-NN entry points (get_knn.py:60-71), the reference's function
     g = torch.Generator().manual_seed(77)
     qe = torch.randn(9, 48, generator=g)
     re_ = torch.randn(301, 48, generator=g)
     for metric in ("l2", "cosine"):
         a, b = (torch.nn.functional.normalize(qe), torch.nn.functional.normalize(re_)) \
             if metric == "cosine" else (qe, re_)
-        dd, ii = ranking.get_knn_torch(b, a, 20, metric)
+        ii, dd = ref_get_knn(b, a, 20, False, with_faiss=False, distance_metric=metric)
         out[f"float_{metric}/q"] = a.numpy()
         out[f"float_{metric}/r"] = b.numpy()
         out[f"float_{metric}/dist"] = dd.numpy()

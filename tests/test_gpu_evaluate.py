@@ -109,3 +109,22 @@ def test_evaluate_on_split_files_through_the_yaml_pipeline(setup, tmp_path):
     ref = ranking.calculate_maphashing(q, dts["test"].label_matrix, r, dts["gallery"].label_matrix, 30, stable=True)
     assert abs(m["test"]["maphashing_level0"] - ref) < 1e-6
     assert {"rpr_level0", "pr_level0", "map_level0"} <= set(m["test"])
+
+
+def test_label_modes_whole_matrix_and_pml_column_slice(setup):
+    """label_hierarchy_level=None (default): the whole multi-hot matrix reaches calculate_maphashing ("shares >= 1 tag",
+    the relevance of studies/measure_random_baseline.py:107).  An int reproduces PML's labels[:, level] slice (then
+    labels are 1-D and compared with ==).  Which of the two the reference's tester effectively applies cannot be
+    checked without pytorch_metric_learning (parity unpinned): both are pinned to the oracle here."""
+    net, dts = setup
+    common = dict(test_dataset=dts, epoch=0, batch_size=16, num_workers=0, k=40, distance_metric="hamming",
+                  exclude=["map", "mean_reciprocal_rank", "precision_at_1", "r_precision", "rpr", "pr", "pr_rc"])
+    whole = evaluate(net, **common)["test"]["maphashing_level0"]
+    col0 = evaluate(net, label_hierarchy_level=0, **common)["test"]["maphashing_level0"]
+    with torch.no_grad():
+        enc = lambda d: net(torch.stack([d[i]["image"] for i in range(len(d))]).cuda()).cpu()
+        q, r = enc(dts["test"]), enc(dts["gallery"])
+    ql, rl = dts["test"].labels, dts["gallery"].labels
+    assert abs(whole - ranking.calculate_maphashing(q, ql, r, rl, 40, stable=True)) < 1e-6
+    assert abs(col0 - ranking.calculate_maphashing(q, ql[:, 0], r, rl[:, 0], 40, stable=True)) < 1e-6
+    assert abs(whole - col0) > 1e-3                               # the two modes are different metrics

@@ -356,3 +356,93 @@ def test_float_knn_select_path_with_ties_across_the_threshold(metric):
     sd, si = ranking.knn_stable(r, q, k, metric)
     assert torch.equal(gi.cpu().long(), si.long())
     assert torch.allclose(gd.cpu(), sd, rtol=1e-6, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------- reference-executed fixtures
+def test_hip_path_against_reference_executed_outputs(gold):
+    """ranking_golden.npz `ref_*` keys = what the reference's own functions returned (tests/golden/make_golden.py cuts
+    accuracy_calculator.py:31-37,183-231 and get_knn.py:9-24,60-71 out of the reference files and runs them)."""
+    for n in cases(gold):
+        q, r = t32(gold[n + "/q"]).cuda(), t32(gold[n + "/r"]).cuda()
+        ql, rl = t32(gold[n + "/ql"]).cuda(), t32(gold[n + "/rl"]).cuda()
+        k, nbits, Q = int(gold[n + "/k"][0]), q.shape[1], q.shape[0]
+        calc = CustomCalculator(k=k, distance_metric="hamming", with_faiss=False)
+        # distances: the reference's fp32 values, bit for bit
+        np.testing.assert_array_equal(calc.calc_hamming_dist(q, r).cpu().numpy(), gold[n + "/ref_dist"])
+        np.testing.assert_array_equal(calc.label_comparison_fn(ql, rl).cpu().numpy(), gold[n + "/ref_gnd"])
+        # ranked lists vs the order the reference's torch.argsort produced: same distance row, same bucket sets
+        idx, dk = H.hamming_topk(H.pack_codes(q), H.pack_codes(r), nbits, k)
+        order = torch.from_numpy(gold[n + "/ref_argsort"]).long()
+        di = torch.from_numpy(gold[n + "/ref_dist"]).round().long()
+        for i in range(Q):
+            un = order[i][:k]
+            assert torch.equal(di[i][un], dk[i].cpu().long())
+            assert ranking.bucket_sets(un, di[i][un]) == ranking.bucket_sets(idx[i].cpu().long(), dk[i].cpu().long())
+        # the reported metric: tie noise only (exact on the tie-free case below)
+        m = calc.calculate_maphashing(q, ql, r, rl, k)
+        m_all = calc.calculate_maphashing(q, ql, r, rl, None)
+        assert abs(m - gold[n + "/ref_map"][0]) < 0.05 and abs(m_all - gold[n + "/ref_map_all"][0]) < 0.05
+        assert abs(calc.calculate_bit_balance(r) - gold[n + "/ref_bit_balance"][0]) < 1e-6
+        assert abs(calc.calculate_worst_bit_balance(r) - gold[n + "/ref_bit_balance"][1]) < 1e-6
+        # get_knn, both source modes: the reference's inner products exactly, its index sets per complete bucket
+        kk = gold[n + "/ref_knn_idx"].shape[1]
+        for same, qq, ki, kd in ((False, q, "ref_knn_idx", "ref_knn_ip"), (True, r[:Q], "ref_selfknn_idx", "ref_selfknn_ip")):
+            i_h, d_h = get_knn(r, qq, kk, same, with_faiss=False, distance_metric="hamming")
+            assert i_h.dtype == torch.int64 and d_h.dtype == torch.float32
+            np.testing.assert_array_equal(d_h.cpu().numpy(), gold[f"{n}/{kd}"])
+            ref_i, ref_d = torch.from_numpy(gold[f"{n}/{ki}"]).long(), torch.from_numpy(gold[f"{n}/{kd}"])
+            for i in range(Q):
+                assert ranking.bucket_sets(i_h[i].cpu(), d_h[i].cpu()) == ranking.bucket_sets(ref_i[i], ref_d[i])
+
+
+def test_tie_free_case_equals_the_reference_exactly(gold):
+    n = "tiefree_q8_n60_b128"
+    q, r = t32(gold[n + "/q"]).cuda(), t32(gold[n + "/r"]).cuda()
+    ql, rl = t32(gold[n + "/ql"]).cuda(), t32(gold[n + "/rl"]).cuda()
+    k = int(gold[n + "/k"][0])
+    idx, _ = H.hamming_topk(H.pack_codes(q), H.pack_codes(r), 128, k)
+    np.testing.assert_array_equal(idx.cpu().numpy(), gold[n + "/ref_argsort"][:, :k])      # the reference's own order
+    calc = CustomCalculator(k=k, distance_metric="hamming", with_faiss=False)
+    assert abs(calc.calculate_maphashing(q, ql, r, rl, k) - gold[n + "/ref_map"][0]) < AP_TOL
+    assert abs(calc.calculate_maphashing(q, ql, r, rl, None) - gold[n + "/ref_map_all"][0]) < AP_TOL
+    i_h, d_h = get_knn(r, q, 20, False, with_faiss=False, distance_metric="hamming")
+    np.testing.assert_array_equal(i_h.cpu().numpy(), gold[n + "/ref_knn_idx"][:, :20])
+
+
+def test_label_comparison_other_branches_match_reference(gold):
+    calc = CustomCalculator(k=5, distance_metric="hamming", with_faiss=False)
+    ql, rl = torch.from_numpy(gold["classid/ql"]).cuda(), torch.from_numpy(gold["classid/rl"]).cuda()
+    np.testing.assert_array_equal(calc.label_comparison_fn(ql, rl).cpu().numpy(), gold["classid/ref_gnd"])
+    ql3, knn = t32(gold["mixed/ql"]).cuda(), t32(gold["mixed/knn_labels"]).cuda()
+    np.testing.assert_array_equal(calc.label_comparison_fn(ql3[:, None], knn).cpu().numpy(), gold["mixed/ref_gnd"])
+    # float k-NN against the reference's get_knn_torch (cdist / matmul + topk): same neighbours (no ties in these)
+    for metric in ("l2", "cosine"):
+        i_h, d_h = get_knn(torch.from_numpy(gold[f"float_{metric}/r"]), torch.from_numpy(gold[f"float_{metric}/q"]), 20,
+                           False, with_faiss=False, distance_metric=metric)
+        np.testing.assert_array_equal(i_h.cpu().numpy(), gold[f"float_{metric}/idx"])
+        np.testing.assert_allclose(d_h.cpu().numpy(), gold[f"float_{metric}/dist"], rtol=2e-5, atol=2e-6)
+
+
+def test_256_bit_codes_cannot_wrap_a_byte_distance():
+    """Complementary 256-bit codes are 256 apart: a uint8 distance would read 0 (the nearest value).  Refused."""
+    q = torch.ones(2, 256)
+    r = -torch.ones(3, 256)
+    calc = CustomCalculator(k=2, distance_metric="hamming", with_faiss=False)
+    with pytest.raises(ValueError, match="nbits <= 255"):
+        calc.calc_hamming_dist(q, r)
+    with pytest.raises(ValueError, match="nbits <= 255"):
+        H.hamming_dist(H.pack_codes(q.cuda()), H.pack_codes(r.cuda()))
+    d = calc.calc_hamming_dist(q[:, :255], r[:, :255])                   # 255 bits: the largest distance fits
+    assert (d == 255).all()
+    d = H.hamming_dist(H.pack_codes(q[:, :200].cuda()), H.pack_codes(r[:, :200].cuda()), nbits=200)
+    assert (d == 200).all()
+
+
+def test_l2_values_follow_the_selected_reference_backend(gold):
+    """get_knn.py: faiss IndexFlatL2 (with_faiss=True, the default) returns SQUARED L2, torch.cdist true L2."""
+    q, r = torch.from_numpy(gold["float_l2/q"]), torch.from_numpy(gold["float_l2/r"])
+    i_t, d_t = get_knn(r, q, 20, False, with_faiss=False, distance_metric="l2")
+    i_f, d_f = get_knn(r, q, 20, False, with_faiss=True, distance_metric="l2")
+    assert torch.equal(i_t, i_f)
+    np.testing.assert_allclose(d_f.cpu().numpy(), d_t.cpu().numpy() ** 2, rtol=1e-6)
+    np.testing.assert_allclose(d_t.cpu().numpy(), gold["float_l2/dist"], rtol=2e-5, atol=2e-6)

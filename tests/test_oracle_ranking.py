@@ -1,6 +1,7 @@
-"""Pins oracle/ranking.py (CPU only): committed golden vectors + the behavioural known answers of
-/root/reference/studies/measure_random_baseline.py (constant codes -> mAP = relevance-driven
-floor; random codes ~ relevance density)."""
+"""Pins oracle/ranking.py (CPU only) to outputs of the REFERENCE'S OWN ranking code: tests/golden/ranking_golden.npz
+holds what accuracy_calculator.py:31-37,183-231 and get_knn.py:9-24,60-71 returned when tests/golden/make_golden.py
+cut those functions out of the reference files and ran them (keys `<case>/ref_*`), plus the behavioural known answers
+of /root/reference/studies/measure_random_baseline.py (constant codes -> mAP = relevance-driven floor)."""
 import numpy as np
 import pytest
 import torch
@@ -24,7 +25,7 @@ def load_case(g, n):
 
 def test_golden_distances_topk_and_map(gold):
     names = case_names(gold)
-    assert len(names) == 4
+    assert len(names) == 5
     for n in names:
         q, r, ql, rl, k = load_case(gold, n)
         d = ranking.calc_hamming_dist(q, r)
@@ -109,3 +110,64 @@ def test_get_knn_shapes_and_same_source(gold):
         d, i = ranking.get_knn_torch(torch.from_numpy(gold[f"float_{m}/r"]), torch.from_numpy(gold[f"float_{m}/q"]), 20, m)
         np.testing.assert_array_equal(i.numpy(), gold[f"float_{m}/idx"])
         np.testing.assert_allclose(d.numpy(), gold[f"float_{m}/dist"], rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------------- reference-executed fixtures
+def _ap_on_order(order, gnd_row, k):
+    """AP formula of accuracy_calculator.py:223-229 on a given ranking."""
+    t = gnd_row[order][:k]
+    n = int(t.sum())
+    if n == 0:
+        return 0.0
+    pos = torch.where(t == 1)[0].float() + 1.0
+    return torch.mean(torch.arange(1, n + 1).float() / pos).item()
+
+
+def test_oracle_reproduces_the_reference_executed_outputs(gold):
+    for n in case_names(gold):
+        q, r, ql, rl, k = load_case(gold, n)
+        ref_d = torch.from_numpy(gold[f"{n}/ref_dist"])
+        assert torch.equal(ranking.calc_hamming_dist(q, r), ref_d)                       # :183-186
+        gnd = ranking.label_comparison_fn(ql, rl)
+        np.testing.assert_array_equal(gnd.numpy(), gold[f"{n}/ref_gnd"])                  # :31-37
+        np.testing.assert_array_equal([ranking.calculate_bit_balance(r), ranking.calculate_worst_bit_balance(r)],
+                                      gold[f"{n}/ref_bit_balance"])                       # :188-200
+        # the reference's own argsort order, replayed through the AP formula, gives the reference's mAP (:203-231)
+        order = torch.from_numpy(gold[f"{n}/ref_argsort"]).long()
+        for kk, key in ((k, "ref_map"), (None, "ref_map_all")):
+            aps = [_ap_on_order(order[i], gnd[i].float(), kk) for i in range(q.shape[0])]
+            assert abs(sum(aps) / len(aps) - gold[f"{n}/{key}"][0]) < 1e-12
+        # canonical order = the reference's order up to permutations inside a distance bucket
+        idx, dk = ranking.hamming_topk_stable(q, r, k)
+        di = ref_d.round().long()
+        for i in range(q.shape[0]):
+            un = order[i][:k]
+            assert torch.equal(di[i][un], dk[i])
+            assert ranking.bucket_sets(un, di[i][un]) == ranking.bucket_sets(idx[i], dk[i])
+        # k-NN: same inner products, same index sets per complete bucket (get_knn.py:9-24, 60-71)
+        ref_ip, ref_i = torch.from_numpy(gold[f"{n}/ref_knn_ip"]), torch.from_numpy(gold[f"{n}/ref_knn_idx"]).long()
+        d_o, i_o = ranking.knn_stable(r, q, ref_ip.shape[1], "hamming")
+        assert torch.equal(d_o, ref_ip)
+        for i in range(q.shape[0]):
+            assert ranking.bucket_sets(i_o[i], d_o[i]) == ranking.bucket_sets(ref_i[i], ref_ip[i])
+        si, sd = ranking.get_knn(r, r[:q.shape[0]], ref_ip.shape[1], True, distance_metric="hamming")
+        np.testing.assert_array_equal(sd.numpy(), gold[f"{n}/ref_selfknn_ip"])
+
+
+def test_tie_free_case_is_exact(gold):
+    """Every distance of a query distinct -> the reference's unstable argsort IS the canonical order."""
+    n = "tiefree_q8_n60_b128"
+    q, r, ql, rl, k = load_case(gold, n)
+    d = ranking.hamming_matrix_u8(q, r)
+    assert all(len(set(row.tolist())) == r.shape[0] for row in d)
+    idx, _ = ranking.hamming_topk_stable(q, r, k)
+    np.testing.assert_array_equal(idx.numpy(), gold[f"{n}/ref_argsort"][:, :k])
+    assert ranking.calculate_maphashing(q, ql, r, rl, k, stable=True) == gold[f"{n}/ref_map"][0]
+
+
+def test_label_comparison_other_branches_match_reference(gold):
+    ql, rl = torch.from_numpy(gold["classid/ql"]), torch.from_numpy(gold["classid/rl"])
+    np.testing.assert_array_equal(ranking.label_comparison_fn(ql, rl).numpy(), gold["classid/ref_gnd"])
+    ql3 = torch.from_numpy(gold["mixed/ql"].astype(np.float32))
+    knn = torch.from_numpy(gold["mixed/knn_labels"].astype(np.float32))
+    np.testing.assert_array_equal(ranking.label_comparison_fn(ql3[:, None], knn).numpy(), gold["mixed/ref_gnd"])

@@ -79,6 +79,15 @@ def _worker(rank, world, port, cases, nbits, ql, out_dir):
             idx, d = parallel.sharded_hamming_topk(_pack(q_all[rank * ql:(rank + 1) * ql]), _pack(r[lo:hi]), nbits,
                                                    k, n_db, trim=trim)
             out[(n_db, k, trim)] = (idx, d)
+        # hinted exchange (no host read): a generous hint is exact and verifies, a hint of 1 entry is flagged
+        shard, kin = _pack(r[lo:hi]), min(k, parallel.shard_bounds(n_db, world, rank)[2])
+        qs = _pack(q_all[rank * ql:(rank + 1) * ql])
+        idx_h, d_h, need = parallel.sharded_hamming_topk(qs, shard, nbits, k, n_db, send_hint=kin, return_need=True)
+        assert torch.equal(idx_h, out[(n_db, k, True)][0]) and torch.equal(d_h, out[(n_db, k, True)][1])
+        assert parallel.exchange_ok([need], kin, kin)
+        if int(need.item()) > 1:
+            *_, need1 = parallel.sharded_hamming_topk(qs, shard, nbits, k, n_db, send_hint=1, return_need=True)
+            assert not parallel.exchange_ok([need1], 1, kin)
     torch.save(out, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
