@@ -20,6 +20,15 @@
 namespace wv {
 
 constexpr int kTopkThreads = 256;
+
+// second-generation kernel (rank2.hip): windowed count table, branch-free, LDS-assembled list
+int rank2_tpq(int Q, int64_t N, int k);
+size_t rank2_image_bytes(int64_t N, int words, int tpq);
+int rank2_prepare(const uint64_t *db, void *img, int64_t N, int words, int tpq, hipStream_t st);
+int rank2_launch(const uint64_t *q, const uint64_t *dbT, int32_t *idx, uint8_t *dist, int Q, int64_t N, int nbits, int k,
+                 int64_t idx_offset, uint32_t *cum, int tpq, hipStream_t st);
+// the one-wave-per-query image exists for databases (shards) of at most this many rows
+constexpr int64_t kImg64MaxRows = 64 * 128;
 __device__ int g_topk_dbg = 0;   // WV_TOPK_DBG (timing experiments only): 1 = no list stores, 2 = skip phase 2, 4 = skip phase 1
 constexpr int kMaxBins = 130;  // nbits <= 128 (+1 bin for the padding value of ragged shard lists)
 
@@ -690,6 +699,19 @@ static int launch_topk(const uint64_t *q, const uint64_t *db, const uint64_t *db
     const int C = (int)ceil_div(N, kTopkThreads);
     const int nbins = nbits + 1;
     const uint64_t *dbT = dbT_ready;
+    if (const int tpq = rank2_tpq(Q, N, k)) {
+        // images: [256 threads per query][64 threads per query (only for N <= kImg64MaxRows)]
+        const size_t img256 = rank2_image_bytes(N, WORDS, 256);
+        const uint64_t *img = nullptr;
+        if (dbT_ready) {
+            img = tpq == 256 ? dbT_ready : (const uint64_t *)((const char *)dbT_ready + align_up((int64_t)img256, 256));
+        } else {
+            int rc0 = rank2_prepare(db, ws, N, WORDS, tpq, st);
+            if (rc0) return rc0;
+            img = (const uint64_t *)ws;
+        }
+        return rank2_launch(q, img, idx, dist, Q, N, nbits, k, idx_offset, cum, tpq, st);
+    }
     if (!dbT) {
         int rc0 = launch_transpose<WORDS>(db, (uint64_t *)ws, N, st);
         if (rc0) return rc0;
@@ -715,13 +737,17 @@ static int launch_topk(const uint64_t *q, const uint64_t *db, const uint64_t *db
 
 size_t topk_prepared_bytes(int64_t N, int words)
 {
-    return (size_t)ceil_div(N, kTopkThreads) * kTopkThreads * words * sizeof(uint64_t);
+    const size_t img256 = (size_t)ceil_div(N, kTopkThreads) * kTopkThreads * words * sizeof(uint64_t);
+    if (N > kImg64MaxRows) return img256;
+    return (size_t)align_up((int64_t)img256, 256) + rank2_image_bytes(N, words, 64);
 }
 
 int topk_prepare(const uint64_t *db, void *dbT, int64_t N, int words, hipStream_t st)
 {
-    if (words == 1) return launch_transpose<1>(db, (uint64_t *)dbT, N, st);
-    return launch_transpose<2>(db, (uint64_t *)dbT, N, st);
+    int rc = words == 1 ? launch_transpose<1>(db, (uint64_t *)dbT, N, st) : launch_transpose<2>(db, (uint64_t *)dbT, N, st);
+    if (rc || N > kImg64MaxRows) return rc;
+    const size_t img256 = (size_t)ceil_div(N, kTopkThreads) * kTopkThreads * words * sizeof(uint64_t);
+    return rank2_prepare(db, (char *)dbT + align_up((int64_t)img256, 256), N, words, 64, st);
 }
 
 }  // namespace wv
@@ -732,7 +758,8 @@ extern "C" size_t wv_hamming_topk_workspace_bytes(int Q, int64_t N, int words, i
 {
     (void)Q; (void)k;
     if (N <= 0 || words <= 0) return 0;
-    return (size_t)ceil_div(N, kTopkThreads) * kTopkThreads * words * sizeof(uint64_t);
+    // one database image, for whichever thread count per query the call takes (the 64-thread one is never smaller)
+    return std::max((size_t)ceil_div(N, kTopkThreads) * kTopkThreads, (size_t)ceil_div(N, 64) * 64) * words * sizeof(uint64_t);
 }
 
 extern "C" int wv_hamming_topk(const uint64_t *q, const uint64_t *db, int32_t *idx, uint8_t *dist,

@@ -55,6 +55,9 @@ def make_net(cls=SharedDinoHashing, nbits=64):
     else:
         net = cls(backbone=tiny_vit(), **kw)
     net.hash_fc.weight.data.mul_(50)                      # spread the logits away from 0
+    for name, prm in net.named_parameters():              # DINOv2 initialises LayerScale at 1e-5: with random weights the
+        if name.endswith(".gamma"):                       # CLS token would barely depend on the image; make it depend
+            prm.data.fill_(1.0)
     return net.cuda().eval()
 
 

@@ -39,6 +39,9 @@ def setup():
               "sub_band_dropout_p": 0, "ortho_weight": 0.1}
     net = SharedDinoHashing({"name": "dinov2_vits14", "frozen": True}, fusion, {"nbits": 64}, backbone=tiny_vit())
     net.hash_fc.weight.data.mul_(50)                      # spread the logits away from 0
+    for name, prm in net.named_parameters():              # LayerScale at DINOv2's 1e-5 init would make the codes
+        if name.endswith(".gamma"):                       # (nearly) independent of the image
+            prm.data.fill_(1.0)
     net = net.cuda().eval().set_wavelet(level=1, wavelet="haar")
     tf = SWTTransform(level=1, wavelet="haar", defer=True)   # workers only size the image; SWT runs batched
     return net, {"test": SynthHashing(24, 1, tf), "gallery": SynthHashing(160, 2, tf)}

@@ -446,3 +446,47 @@ def test_l2_values_follow_the_selected_reference_backend(gold):
     assert torch.equal(i_t, i_f)
     np.testing.assert_allclose(d_f.cpu().numpy(), d_t.cpu().numpy() ** 2, rtol=1e-6)
     np.testing.assert_allclose(d_t.cpu().numpy(), gold["float_l2/dist"], rtol=2e-5, atol=2e-6)
+
+
+# ---------------------------------------------------------------------------------- windowed kernel (rank2.hip)
+def _spread_codes(Q, N, nbits, seed):
+    """Distances of every query spread over (nearly) all bins: row j differs from a base code in j % (nbits + 1) bits,
+    queries differ from it in a few more -- the ranking needs several 32-bin windows."""
+    g = torch.Generator().manual_seed(seed)
+    base = torch.randint(0, 2, (nbits,), generator=g).float() * 2 - 1
+    r = base.repeat(N, 1)
+    flips = torch.randint(0, nbits + 1, (N,), generator=g)
+    for j in range(N):
+        pos = torch.randperm(nbits, generator=g)[:int(flips[j])]
+        r[j, pos] *= -1
+    q = base.repeat(Q, 1)
+    for i in range(Q):
+        pos = torch.randperm(nbits, generator=g)[:i % 7]
+        q[i, pos] *= -1
+    return q, r
+
+
+@pytest.mark.parametrize("variant", ["256", "64", "0"])
+@pytest.mark.parametrize("Q,N,nbits,k", [(9, 3000, 64, 2500), (5, 3000, 128, 3000), (33, 1000, 64, 37), (6, 257, 32, 257),
+                                          (4100, 700, 64, 200)])
+def test_window_kernel_variants_and_multi_window_rankings(monkeypatch, variant, Q, N, nbits, k):
+    """WV_TOPK_V2 pins the implementation: 256 / 64 threads per query of the windowed kernel, 0 = first-generation
+    kernel.  Spread distances force the window to slide; lists, distance rows and histograms must not change."""
+    monkeypatch.setenv("WV_TOPK_V2", variant)
+    q, r = (_spread_codes(Q, N, nbits, seed=N + nbits) if Q < 100 else synth.random_codes(Q, N, nbits, seed=5))
+    qp, rp = H.pack_codes(q.cuda()), H.pack_codes(r.cuda())
+    ref_idx, ref_d = ranking.hamming_topk_stable(q[:64], r, k)
+    for db in (rp, H.PreparedDB(rp, nbits)):
+        idx, d = H.hamming_topk(qp, db, nbits, k, idx_offset=1000)
+        assert torch.equal(idx[:64].cpu().long() - 1000, ref_idx) and torch.equal(d[:64].cpu().long(), ref_d)
+        idx2, d2, cum = H.hamming_topk(qp, db, nbits, k, want_cum=True)
+        assert torch.equal(idx2 + 1000, idx) and torch.equal(d2, d)
+        dm = ranking.hamming_matrix_u8(q[:64], r)
+        ref_cum = torch.stack([(dm < b).sum(1) for b in range(nbits + 2)], dim=1)
+        assert torch.equal(cum[:64].cpu().long(), ref_cum)
+        if Q > 64:                                               # every query: sorted, consistent with the matrix
+            full = H.hamming_dist(qp, rp, nbits=nbits)
+            assert torch.equal(torch.gather(full, 1, (idx - 1000).long()), d)
+            assert (d[:, 1:] >= d[:, :-1]).all()
+            same = d[:, 1:] == d[:, :-1]
+            assert (idx[:, 1:][same] > idx[:, :-1][same]).all()
