@@ -14,11 +14,28 @@
 //     (global index = item + idx_offset), the distance row is regenerated from the bin boundaries, 16 bytes per store;
 //   * TPQ = 64 runs one query per WAVE (no workgroup barrier at all, 4 queries per workgroup): the shape of a
 //     row-sharded search, many queries against few rows each.
+//   * the database image is the traffic that matters (phase stamps: 70 % of the first windowed version went into loading
+//     it -- every query's workgroup streams the whole image from L2, 410 MB per launch at c1): a group now computes the
+//     distances of QB queries from ONE pass over the image (the queries are then ranked one after the other through the
+//     same LDS), and a lane loads 16 bytes (two 64-bit codes) per instruction;
 // Covers N < 65536 (16-bit item numbers / counters), C <= 128 items per thread (distances cached in registers as
 // bytes), k small enough for the LDS list; everything else stays on topk.hip's kernel.
 #include "common.hpp"
 
 namespace wv {
+
+// Diagnostic build only (-DWV_RANK2_STAMPS, tools/build_variant.sh): cycles per phase, summed over wave 0 of every query
+// group into a device array that nothing else reads.
+#ifdef WV_RANK2_STAMPS
+__device__ unsigned long long g_rank2_stamps[8];
+#define R2_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_s_waitcnt(0xC07F); if (t == 0) atomicAdd(&g_rank2_stamps[i], now_ - stamp_); stamp_ = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_sched_barrier(0); } while (0)
+#define R2_STAMP_INIT unsigned long long stamp_ = __builtin_amdgcn_s_memtime()
+#else
+#define R2_STAMP(i) do { } while (0)
+#define R2_STAMP_INIT do { } while (0)
+#endif
 
 constexpr int kWinBins = 32;                 // distance bins per window
 constexpr int kWinRows = kWinBins + 1;       // + the dummy row
@@ -66,14 +83,69 @@ __host__ __device__ inline size_t rank2_lds_bytes_per_query(int k)
     return (b + 15) / 16 * 16;
 }
 
-// NC = distance-cache words (4 items each): items per thread C <= 4 * NC
-template <int WORDS, int TPQ, int NC>
-__device__ __forceinline__ void rank2_one_query(const uint64_t *__restrict__ dbT, const QCode<WORDS> &qc, int64_t N, int C,
-                                                int nbins, int k, int64_t idx_offset, int32_t *__restrict__ idx_out,
-                                                uint8_t *__restrict__ dist_out, uint32_t *__restrict__ cum_out,
-                                                uint8_t *lds_raw, int t)
+// One pass over the database image: distances of QB queries -> bytes in registers (dc[qq][i/4] byte i%4 = item i of this
+// thread; 255 = no item), and this thread's smallest distance per query.
+// Image (rank2_prepare): 16 bytes per (row, thread): two consecutive 64-bit codes of the thread, or one 128-bit code.
+template <int WORDS, int TPQ, int NC, int QB>
+__device__ __forceinline__ void rank2_distances(const uint4 *__restrict__ img, const QCode<WORDS> (&qc)[QB], int64_t N, int C,
+                                                int t, uint32_t (&dc)[QB][NC], uint32_t (&dmin)[QB])
 {
-    constexpr int UNR = 8;
+    constexpr int UNR = 8;                                       // items per batch
+    constexpr int LPB = WORDS == 1 ? UNR / 2 : UNR;              // 16-byte loads per batch
+    const int first = t * C;
+    const int nvalid = min(C, max(0, (int)N - first));           // N < 65536, first <= 256 * 128: plain ints
+    const int rows = WORDS == 1 ? (C + 1) / 2 : C;               // image rows
+#pragma unroll
+    for (int qq = 0; qq < QB; ++qq) {
+        dmin[qq] = 255;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) dc[qq][i] = 0xffffffffu;
+    }
+#pragma unroll
+    for (int bi = 0; bi < (NC * 4 + UNR - 1) / UNR; ++bi) {
+        if (bi * UNR < C) {                                      // uniform
+            uint4 raw[LPB];
+#pragma unroll
+            for (int u = 0; u < LPB; ++u) raw[u] = img[(int64_t)min(bi * LPB + u, rows - 1) * TPQ + t];
+#pragma unroll
+            for (int qq = 0; qq < QB; ++qq) {
+#pragma unroll
+                for (int u4 = 0; u4 < UNR / 4; ++u4) {
+                    if (bi * (UNR / 4) + u4 >= NC) continue;     // NC odd: the last batch has one cache word
+                    uint32_t word = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int u = 4 * u4 + j;
+                        uint32_t d;
+                        if constexpr (WORDS == 1) {
+                            const uint4 v = raw[u >> 1];
+                            const uint32_t lo32 = (u & 1) ? v.z : v.x, hi32 = (u & 1) ? v.w : v.y;
+                            d = (uint32_t)__popc(lo32 ^ (uint32_t)qc[qq].w[0]) + (uint32_t)__popc(hi32 ^ (uint32_t)(qc[qq].w[0] >> 32));
+                        } else {
+                            const uint4 v = raw[u];
+                            d = (uint32_t)__popc(v.x ^ (uint32_t)qc[qq].w[0]) + (uint32_t)__popc(v.y ^ (uint32_t)(qc[qq].w[0] >> 32)) +
+                                (uint32_t)__popc(v.z ^ (uint32_t)qc[qq].w[1]) + (uint32_t)__popc(v.w ^ (uint32_t)(qc[qq].w[1] >> 32));
+                        }
+                        d = (bi * UNR + u < nvalid) ? d : 255u;  // select, not a branch
+                        dmin[qq] = min(dmin[qq], d);
+                        word |= d << (8 * j);
+                    }
+                    dc[qq][bi * (UNR / 4) + u4] = word;
+                }
+            }
+        }
+    }
+}
+
+// Ranks ONE query from its cached distances.  Ends with a group barrier: the LDS region may be reused at once.
+// NC = distance-cache words (4 items each): items per thread C <= 4 * NC
+template <int TPQ, int NC>
+__device__ __forceinline__ void rank2_one_query(const uint32_t (&dc)[NC], uint32_t dmin, int64_t N, int C,
+                                                int nbins, int k, int64_t idx_offset, int32_t *__restrict__ idx_out,
+                                                uint16_t *__restrict__ rows16_out, uint8_t *__restrict__ dist_out,
+                                                uint32_t *__restrict__ cum_out, uint8_t *lds_raw, int t)
+{
+    // k == 0: histogram only (cum_out), no list.  rows16_out: the list as 16-bit LOCAL row numbers instead of idx_out.
     constexpr int ROWB = TPQ * 2;                                // bytes per table row
     Rank2Lds L;
     L.table = reinterpret_cast<uint32_t *>(lds_raw);
@@ -85,47 +157,8 @@ __device__ __forceinline__ void rank2_one_query(const uint64_t *__restrict__ dbT
     L.misc = L.tot + kWinBins;
     const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform
     constexpr int NW = TPQ / 64;                                 // waves per query
-
-    // ---------------------------------------------------------------- phase 0: distances -> registers (bytes)
+    R2_STAMP_INIT;
     const int first = t * C;
-    const int nvalid = (int)min((int64_t)C, max((int64_t)0, N - (int64_t)first));
-    uint32_t dc[NC];
-#pragma unroll
-    for (int i = 0; i < NC; ++i) dc[i] = 0xffffffffu;            // 255 = "no item": never inside a window
-    uint32_t dmin = 255;
-#pragma unroll
-    for (int bi = 0; bi < NC * 4 / UNR; ++bi) {
-        if (bi * UNR < C) {                                      // uniform
-            QCode<WORDS> cur[UNR];
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int r = min(bi * UNR + u, C - 1);
-                const uint64_t *src = dbT + ((int64_t)r * TPQ + t) * WORDS;
-                if constexpr (WORDS == 2) {
-                    const uint4 v = *reinterpret_cast<const uint4 *>(src);
-                    cur[u].w[0] = (uint64_t)v.x | ((uint64_t)v.y << 32);
-                    cur[u].w[1] = (uint64_t)v.z | ((uint64_t)v.w << 32);
-                } else {
-                    cur[u].w[0] = src[0];
-                }
-            }
-#pragma unroll
-            for (int u4 = 0; u4 < UNR / 4; ++u4) {
-                uint32_t word = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int u = 4 * u4 + j;
-                    uint32_t d = 0;
-#pragma unroll
-                    for (int w = 0; w < WORDS; ++w) d += (uint32_t)__popcll(cur[u].w[w] ^ qc.w[w]);
-                    d = (bi * UNR + u < nvalid) ? d : 255u;      // select, not a branch
-                    dmin = min(dmin, d);
-                    word |= d << (8 * j);
-                }
-                dc[bi * (UNR / 4) + u4] = word;
-            }
-        }
-    }
     // smallest distance of the query = first bin of the first window
     dmin = wave_min_u32(dmin);
     if constexpr (NW > 1) {
@@ -137,12 +170,16 @@ __device__ __forceinline__ void rank2_one_query(const uint64_t *__restrict__ dbT
     for (int b = t; b <= nbins; b += TPQ) L.gbase[b] = b <= (int)dmin ? 0u : 0xffffffffu;
     int lo = min((int)dmin, nbins - 1);                          // dmin == 255 cannot happen (N >= 1)
     uint32_t placed = 0;                                         // rows with distance < lo
-    const uint32_t cell_addr = (uint32_t)(t >> 1) * 4u;          // byte offset of this thread's dword inside a row
-    const uint32_t cell_inc = 1u << (16 * (t & 1));
-    const uint32_t cell_shift = 16u * (t & 1);
+    // Cell of thread t inside a table row: dword (t>>6)*32 + (t&31), half (t>>5)&1 -- lanes l and l+32 of a wave share a
+    // dword.  A wave's LDS instruction is served in two groups of 32 lanes; this way each group touches 32 different
+    // banks whatever the bins are (pairing lanes 2j, 2j+1 instead made every atomic a 2-way conflict).
+    const uint32_t cell_addr = (uint32_t)((t >> 6) * 32 + (t & 31)) * 4u;
+    const uint32_t cell_shift = 16u * ((t >> 5) & 1);
+    const uint32_t cell_inc = 1u << cell_shift;
     char *tbl = reinterpret_cast<char *>(L.table);
     const uint32_t trash = (uint32_t)(k + t);
 
+    R2_STAMP(0);
     for (;;) {
         const bool place = placed < (uint32_t)k;                 // uniform: false = count-only pass (cum requested)
         // ---- zero the table
@@ -170,13 +207,14 @@ __device__ __forceinline__ void rank2_one_query(const uint64_t *__restrict__ dbT
             }
         }
         group_sync<TPQ>();
+        R2_STAMP(1);
         // ---- per-bin totals (the waves of the group share the bins)
         for (int b = wv; b < kWinBins; b += NW) {
             uint32_t s;
             if constexpr (TPQ == 64) {
-                s = (L.table[b * (TPQ / 2) + (lane >> 1)] >> cell_shift) & 0xffffu;
+                s = (L.table[b * (TPQ / 2) + (lane & 31)] >> cell_shift) & 0xffffu;
             } else {
-                const uint2 v = *reinterpret_cast<const uint2 *>(L.table + b * (TPQ / 2) + 2 * lane);
+                const uint2 v = *reinterpret_cast<const uint2 *>(L.table + b * (TPQ / 2) + 2 * lane);   // any 4 cells
                 s = (v.x & 0xffffu) + (v.x >> 16) + (v.y & 0xffffu) + (v.y >> 16);
             }
             s = wave_sum_u32(s);
@@ -193,18 +231,22 @@ __device__ __forceinline__ void rank2_one_query(const uint64_t *__restrict__ dbT
             for (int b = wv; b < kWinBins; b += NW) {
                 const uint32_t base_b = (uint32_t)__builtin_amdgcn_readlane((int)bin_base, b);
                 if constexpr (TPQ == 64) {
-                    const uint32_t c = (L.table[b * (TPQ / 2) + (lane >> 1)] >> cell_shift) & 0xffffu;
+                    const uint32_t c = (L.table[b * (TPQ / 2) + (lane & 31)] >> cell_shift) & 0xffffu;
                     const uint32_t excl = wave_incl_scan_u32(c) - c + base_b;
-                    reinterpret_cast<uint16_t *>(L.table + b * (TPQ / 2))[lane] = (uint16_t)min(excl, 0xffffu);
+                    reinterpret_cast<uint16_t *>(L.table + b * (TPQ / 2))[2 * (lane & 31) + (lane >> 5)] =
+                        (uint16_t)min(excl, 0xffffu);
                 } else {
-                    uint2 v = *reinterpret_cast<const uint2 *>(L.table + b * (TPQ / 2) + 2 * lane);
-                    const uint32_t c0 = v.x & 0xffffu, c1 = v.x >> 16, c2 = v.y & 0xffffu, c3 = v.y >> 16;
+                    // lane L scans threads 4L .. 4L+3: four consecutive dwords of the row, the same half of each
+                    const int t0 = 4 * lane, d0 = (t0 >> 6) * 32 + (t0 & 31), sh = 16 * ((t0 >> 5) & 1);
+                    const uint4 v = *reinterpret_cast<const uint4 *>(L.table + b * (TPQ / 2) + d0);
+                    const uint32_t c0 = (v.x >> sh) & 0xffffu, c1 = (v.y >> sh) & 0xffffu, c2 = (v.z >> sh) & 0xffffu,
+                                   c3 = (v.w >> sh) & 0xffffu;
                     const uint32_t s = c0 + c1 + c2 + c3;
                     const uint32_t e0 = wave_incl_scan_u32(s) - s + base_b;
                     const uint32_t e1 = e0 + c0, e2 = e1 + c1, e3 = e2 + c2;
-                    v.x = (e0 & 0xffffu) | (e1 << 16);
-                    v.y = (e2 & 0xffffu) | (e3 << 16);
-                    *reinterpret_cast<uint2 *>(L.table + b * (TPQ / 2) + 2 * lane) = v;
+                    // the other half of these dwords belongs to another lane: 16-bit stores
+                    uint16_t *h = reinterpret_cast<uint16_t *>(L.table + b * (TPQ / 2) + d0) + (sh >> 4);
+                    h[0] = (uint16_t)e0; h[2] = (uint16_t)e1; h[4] = (uint16_t)e2; h[6] = (uint16_t)e3;
                 }
             }
             // dummy row: every cell starts at k, so whatever it returns is >= k (trash); k + 128 < 65536 (host check)
@@ -213,6 +255,7 @@ __device__ __forceinline__ void rank2_one_query(const uint64_t *__restrict__ dbT
                 for (int i = lane; i < TPQ / 2; i += 64) L.table[kWinBins * (TPQ / 2) + i] = kk;
             }
             group_sync<TPQ>();
+            R2_STAMP(2);
             // ---- placement: returning LDS add = this item's rank, item number into the LDS list (or the trash slot)
 #pragma unroll
             for (int bw = 0; bw < NC; bw += 2) {
@@ -239,6 +282,7 @@ __device__ __forceinline__ void rank2_one_query(const uint64_t *__restrict__ dbT
                 }
             }
         }
+        R2_STAMP(3);
         placed += win_total;
         lo += kWinBins;
         // uniform exit: the list is complete and nobody asked for the full histogram, or no bins are left
@@ -250,8 +294,17 @@ __device__ __forceinline__ void rank2_one_query(const uint64_t *__restrict__ dbT
     // ---- cumulative histogram of all rows (cum[b] = rows with distance < b), for the sharded search
     if (cum_out)
         for (int b = t; b <= nbins; b += TPQ) cum_out[b] = min(L.gbase[b], (uint32_t)N);
+    R2_STAMP(4);
     // ---- the ranked list leaves with 16-byte stores
-    {
+    if (rows16_out) {
+        if ((k & 7) == 0 && (reinterpret_cast<uintptr_t>(rows16_out) & 15) == 0) {
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(L.stage);
+            uint4 *o4 = reinterpret_cast<uint4 *>(rows16_out);
+            for (int i = t; i < k / 8; i += TPQ) o4[i] = s4[i];
+        } else {
+            for (int i = t; i < k; i += TPQ) rows16_out[i] = L.stage[i];
+        }
+    } else if (idx_out) {
         const bool vec = (k & 3) == 0 && (reinterpret_cast<uintptr_t>(idx_out) & 15) == 0;
         const int32_t off = (int32_t)idx_offset;
         if (vec) {
@@ -308,48 +361,72 @@ __device__ __forceinline__ void rank2_one_query(const uint64_t *__restrict__ dbT
             }
         }
     }
+    R2_STAMP(5);
+    group_sync<TPQ>();                                            // the next query of the group reuses this LDS
 }
 
-// dbT image for TPQ threads per query: dbT[r][t] = code[t*C + r], C = ceil(N / TPQ); rows beyond N are zero
+// Image for TPQ threads per query, 16 bytes per (row, thread).  64-bit codes: row r2 of thread t = its items 2*r2 and
+// 2*r2 + 1 (item = t*C + i, C = ceil(N / TPQ)); 128-bit codes: row r = item r.  Items beyond the thread's range or beyond
+// N are zero (the kernel masks them by index, never by value).
 template <int WORDS>
-__global__ __launch_bounds__(256) void k_transpose_db2(const uint64_t *__restrict__ db, uint64_t *__restrict__ dbT,
-                                                       int64_t N, int C, int tpq)
+__global__ __launch_bounds__(256) void k_rank2_image(const uint64_t *__restrict__ db, uint4 *__restrict__ img, int64_t N,
+                                                     int C, int tpq)
 {
-    const int64_t total = (int64_t)C * tpq;
+    const int rows = WORDS == 1 ? (C + 1) / 2 : C;
+    const int64_t total = (int64_t)rows * tpq;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / tpq;
         const int t = (int)(i - r * tpq);
-        const int64_t item = (int64_t)t * C + r;
-#pragma unroll
-        for (int w = 0; w < WORDS; ++w) dbT[i * WORDS + w] = item < N ? db[item * WORDS + w] : 0ull;
+        uint64_t a = 0, b = 0;
+        if constexpr (WORDS == 1) {
+            const int64_t i0 = 2 * r, i1 = 2 * r + 1, it0 = (int64_t)t * C + i0, it1 = (int64_t)t * C + i1;
+            if (i0 < C && it0 < N) a = db[it0];
+            if (i1 < C && it1 < N) b = db[it1];
+        } else {
+            const int64_t it = (int64_t)t * C + r;
+            if (it < N) { a = db[it * 2]; b = db[it * 2 + 1]; }
+        }
+        img[i] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
     }
 }
 
 // minimum waves per SIMD the register allocation has to leave room for (the LDS footprint admits at least as many)
-constexpr int rank2_min_waves(int nc, int tpq) { return nc <= 8 ? (tpq == 64 ? 8 : 7) : (nc <= 16 ? 6 : (nc <= 25 ? 5 : 4)); }
+constexpr int rank2_min_waves(int nc, int qb) { return nc * qb <= 8 ? 7 : (nc * qb <= 16 ? 6 : (nc * qb <= 25 ? 5 : (nc * qb <= 32 ? 4 : 3))); }
 
-template <int WORDS, int TPQ, int NC>
-__global__ __launch_bounds__(256, rank2_min_waves(NC, TPQ)) void k_rank_window(const uint64_t *__restrict__ q, const uint64_t *__restrict__ dbT,
-                                                     int32_t *__restrict__ idx, uint8_t *__restrict__ dist, int Q,
-                                                     int64_t N, int C, int nbins, int k, int64_t idx_offset,
-                                                     uint32_t *__restrict__ cum, int lds_per_query)
+template <int WORDS, int TPQ, int NC, int QB>
+__global__ __launch_bounds__(256, rank2_min_waves(NC, QB)) void k_rank_window(const uint64_t *__restrict__ q, const uint4 *__restrict__ img,
+                                                     int32_t *__restrict__ idx, uint16_t *__restrict__ rows16,
+                                                     uint8_t *__restrict__ dist, int Q, int64_t N, int C, int nbins, int k,
+                                                     int64_t idx_offset, uint32_t *__restrict__ cum, int lds_per_group)
 {
     extern __shared__ uint4 lds4[];
-    constexpr int QPW = 256 / TPQ;                              // queries per workgroup
+    constexpr int GPW = 256 / TPQ;                              // query groups per workgroup
     const int g = threadIdx.x / TPQ, t = threadIdx.x % TPQ;
-    const int qi = blockIdx.x * QPW + g;
-    if (QPW > 1 && qi >= Q) return;                              // whole waves only (TPQ == 64): no barrier is skipped
-    QCode<WORDS> qc;
+    const int q0 = (blockIdx.x * GPW + g) * QB;                 // first query of this group
+    if (GPW > 1 && q0 >= Q) return;                              // whole waves only (TPQ == 64): no barrier is skipped
+    QCode<WORDS> qc[QB];
 #pragma unroll
-    for (int w = 0; w < WORDS; ++w) {
-        const uint64_t v = q[(int64_t)qi * WORDS + w];
-        // the query is uniform over its group: keep it in SGPRs
-        qc.w[w] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
-                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    for (int qq = 0; qq < QB; ++qq) {
+        const int qi = min(q0 + qq, Q - 1);                      // tail group: recompute the last query, never store it twice
+#pragma unroll
+        for (int w = 0; w < WORDS; ++w) {
+            const uint64_t v = q[(int64_t)qi * WORDS + w];
+            // the query is uniform over its group: keep it in SGPRs
+            qc[qq].w[w] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+        }
     }
-    rank2_one_query<WORDS, TPQ, NC>(dbT, qc, N, C, nbins, k, idx_offset, idx + (int64_t)qi * k,
-                                    dist ? dist + (int64_t)qi * k : nullptr, cum ? cum + (int64_t)qi * (nbins + 1) : nullptr,
-                                    reinterpret_cast<uint8_t *>(lds4) + (size_t)g * lds_per_query, t);
+    uint32_t dc[QB][NC], dmin[QB];
+    rank2_distances<WORDS, TPQ, NC, QB>(img, qc, N, C, t, dc, dmin);
+    uint8_t *lds = reinterpret_cast<uint8_t *>(lds4) + (size_t)g * lds_per_group;
+#pragma unroll
+    for (int qq = 0; qq < QB; ++qq) {
+        const int qi = q0 + qq;
+        if (qi < Q)                                              // uniform over the group (and over the workgroup when TPQ = 256)
+            rank2_one_query<TPQ, NC>(dc[qq], dmin[qq], N, C, nbins, k, idx_offset, idx ? idx + (int64_t)qi * k : nullptr,
+                                     rows16 ? rows16 + (int64_t)qi * k : nullptr, dist ? dist + (int64_t)qi * k : nullptr,
+                                     cum ? cum + (int64_t)qi * (nbins + 1) : nullptr, lds, t);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -359,8 +436,8 @@ int rank2_tpq(int Q, int64_t N, int k)
     const char *force = getenv("WV_TOPK_V2");                   // "0": off, "64" / "256": pin the variant (tests, tuning)
     if (force && force[0] == '0') return 0;
     if (N >= 65536 || k + 128 >= 65536) return 0;
-    const bool fits256 = ceil_div(N, 256) <= 128 && rank2_lds_bytes_per_query<256>(k) <= 100 * 1024;
-    const bool fits64 = ceil_div(N, 64) <= 128 && 4 * rank2_lds_bytes_per_query<64>(k) <= 100 * 1024;
+    const bool fits256 = N <= 256 * 128 && rank2_lds_bytes_per_query<256>(k) <= 100 * 1024;
+    const bool fits64 = ceil_div(N, 64) <= 64 && 4 * rank2_lds_bytes_per_query<64>(k) <= 100 * 1024;
     if (force && atoi(force) == 64) return fits64 ? 64 : 0;
     if (force && atoi(force) == 256) return fits256 ? 256 : 0;
     // one wave per query pays when each query has little work and there are enough queries to fill the chip
@@ -370,63 +447,93 @@ int rank2_tpq(int Q, int64_t N, int k)
 
 size_t rank2_image_bytes(int64_t N, int words, int tpq)
 {
-    return (size_t)ceil_div(N, tpq) * tpq * words * sizeof(uint64_t);
+    const int64_t C = ceil_div(N, tpq), rows = words == 1 ? (C + 1) / 2 : C;
+    return (size_t)rows * tpq * 16;
 }
 
 int rank2_prepare(const uint64_t *db, void *img, int64_t N, int words, int tpq, hipStream_t st)
 {
     const int C = (int)ceil_div(N, tpq);
-    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div((int64_t)C * tpq, 256), 4096);
+    const int64_t total = (int64_t)(words == 1 ? (C + 1) / 2 : C) * tpq;
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(total, 256), 4096);
     if (words == 1)
-        hipLaunchKernelGGL((k_transpose_db2<1>), dim3(grid), dim3(256), 0, st, db, (uint64_t *)img, N, C, tpq);
+        hipLaunchKernelGGL((k_rank2_image<1>), dim3(grid), dim3(256), 0, st, db, (uint4 *)img, N, C, tpq);
     else
-        hipLaunchKernelGGL((k_transpose_db2<2>), dim3(grid), dim3(256), 0, st, db, (uint64_t *)img, N, C, tpq);
-    WV_CHECK_LAUNCH("k_transpose_db2");
+        hipLaunchKernelGGL((k_rank2_image<2>), dim3(grid), dim3(256), 0, st, db, (uint4 *)img, N, C, tpq);
+    WV_CHECK_LAUNCH("k_rank2_image");
     return WV_OK;
 }
 
-template <int WORDS, int TPQ, int NC>
-static int launch_rank2_nc(const uint64_t *q, const uint64_t *dbT, int32_t *idx, uint8_t *dist, int Q, int64_t N, int C,
-                           int nbins, int k, int64_t idx_offset, uint32_t *cum, hipStream_t st)
+template <int WORDS, int TPQ, int NC, int QB>
+static int launch_rank2_qb(const uint64_t *q, const void *img, int32_t *idx, uint16_t *rows16, uint8_t *dist, int Q, int64_t N,
+                           int C, int nbins, int k, int64_t idx_offset, uint32_t *cum, hipStream_t st)
 {
-    constexpr int QPW = 256 / TPQ;
-    const size_t per_q = rank2_lds_bytes_per_query<TPQ>(k), lds = per_q * QPW;
-    auto kern = k_rank_window<WORDS, TPQ, NC>;
+    constexpr int GPW = 256 / TPQ;
+    const size_t per_g = rank2_lds_bytes_per_query<TPQ>(k), lds = per_g * GPW;
+    auto kern = k_rank_window<WORDS, TPQ, NC, QB>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) WV_FAIL(WV_EHIP, "rank_window: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(Q, QPW)), dim3(256), lds, st, q, dbT, idx, dist, Q, N, C, nbins, k,
-                       idx_offset, cum, (int)per_q);
+    hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(Q, GPW * QB)), dim3(256), lds, st, q, (const uint4 *)img, idx, rows16, dist,
+                       Q, N, C, nbins, k, idx_offset, cum, (int)per_g);
     WV_CHECK_LAUNCH("k_rank_window");
     return WV_OK;
 }
 
+template <int WORDS, int TPQ, int NC, int QBMAX>
+static int launch_rank2_nc(const uint64_t *q, const void *img, int32_t *idx, uint16_t *rows16, uint8_t *dist, int Q, int64_t N,
+                           int C, int nbins, int k, int64_t idx_offset, uint32_t *cum, hipStream_t st)
+{
+    // Sharing one pass over the image between QBMAX queries of a group (ranked one after the other) was measured on
+    // MI355X and is slower at every shape tried (c1: 66 vs 50 us; 16384 x 3125: 176 vs 145 us): the registers of the
+    // extra distance caches cost more occupancy than the saved L2 reads are worth.  The kernel keeps the template
+    // parameter; only QB = 1 is instantiated.
+    (void)QBMAX;
+    return launch_rank2_qb<WORDS, TPQ, NC, 1>(q, img, idx, rows16, dist, Q, N, C, nbins, k, idx_offset, cum, st);
+}
+
 template <int WORDS, int TPQ>
-static int launch_rank2_t(const uint64_t *q, const uint64_t *dbT, int32_t *idx, uint8_t *dist, int Q, int64_t N, int nbins,
-                          int k, int64_t idx_offset, uint32_t *cum, hipStream_t st)
+static int launch_rank2_t(const uint64_t *q, const void *img, int32_t *idx, uint16_t *rows16, uint8_t *dist, int Q, int64_t N,
+                          int nbins, int k, int64_t idx_offset, uint32_t *cum, hipStream_t st)
 {
     const int C = (int)ceil_div(N, TPQ);
-#define WV_R2(NCW) return launch_rank2_nc<WORDS, TPQ, NCW>(q, dbT, idx, dist, Q, N, C, nbins, k, idx_offset, cum, st)
-    if (C <= 16) WV_R2(4);
-    if (C <= 32) WV_R2(8);
-    if (C <= 64) WV_R2(16);
-    if (C <= 100) WV_R2(25);
-    WV_R2(32);
+#define WV_R2(NCW, QBM) return launch_rank2_nc<WORDS, TPQ, NCW, QBM>(q, img, idx, rows16, dist, Q, N, C, nbins, k, idx_offset, cum, st)
+    if (C <= 16) WV_R2(4, 8);
+    if (C <= 32) WV_R2(8, 4);
+    if (C <= 64) WV_R2(16, 2);
+    if constexpr (TPQ == 256) {
+        if (C <= 100) WV_R2(25, 2);
+        WV_R2(32, 2);
+    } else {
+        return 1;                                                // one wave per query is for short rows only
+    }
 #undef WV_R2
 }
 
-// dbT must be the image for `tpq` threads per query (rank2_prepare)
-int rank2_launch(const uint64_t *q, const uint64_t *dbT, int32_t *idx, uint8_t *dist, int Q, int64_t N, int nbits, int k,
-                 int64_t idx_offset, uint32_t *cum, int tpq, hipStream_t st)
+// img must be the image for `tpq` threads per query (rank2_prepare)
+// idx (int32 global indices) or rows16 (16-bit local row numbers) receives the list; k == 0: histogram only
+int rank2_launch(const uint64_t *q, const void *img, int32_t *idx, uint16_t *rows16, uint8_t *dist, int Q, int64_t N, int nbits,
+                 int k, int64_t idx_offset, uint32_t *cum, int tpq, hipStream_t st)
 {
     const int nbins = nbits + 1, words = (nbits + 63) / 64;
     if (words == 1) {
-        if (tpq == 64) return launch_rank2_t<1, 64>(q, dbT, idx, dist, Q, N, nbins, k, idx_offset, cum, st);
-        return launch_rank2_t<1, 256>(q, dbT, idx, dist, Q, N, nbins, k, idx_offset, cum, st);
+        if (tpq == 64) return launch_rank2_t<1, 64>(q, img, idx, rows16, dist, Q, N, nbins, k, idx_offset, cum, st);
+        return launch_rank2_t<1, 256>(q, img, idx, rows16, dist, Q, N, nbins, k, idx_offset, cum, st);
     }
-    if (tpq == 64) return launch_rank2_t<2, 64>(q, dbT, idx, dist, Q, N, nbins, k, idx_offset, cum, st);
-    return launch_rank2_t<2, 256>(q, dbT, idx, dist, Q, N, nbins, k, idx_offset, cum, st);
+    if (tpq == 64) return launch_rank2_t<2, 64>(q, img, idx, rows16, dist, Q, N, nbins, k, idx_offset, cum, st);
+    return launch_rank2_t<2, 256>(q, img, idx, rows16, dist, Q, N, nbins, k, idx_offset, cum, st);
 }
 
 }  // namespace wv
+
+#ifdef WV_RANK2_STAMPS
+// diagnostic build only: read and reset the phase cycle sums (host array of 8)
+extern "C" int wv_debug_rank2_stamps(unsigned long long *host8)
+{
+    if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(wv::g_rank2_stamps), 8 * sizeof(unsigned long long)) != hipSuccess) return -5;
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(wv::g_rank2_stamps), zero, sizeof(zero)) != hipSuccess) return -5;
+    return 0;
+}
+#endif

@@ -25,10 +25,19 @@ constexpr int kTopkThreads = 256;
 int rank2_tpq(int Q, int64_t N, int k);
 size_t rank2_image_bytes(int64_t N, int words, int tpq);
 int rank2_prepare(const uint64_t *db, void *img, int64_t N, int words, int tpq, hipStream_t st);
-int rank2_launch(const uint64_t *q, const uint64_t *dbT, int32_t *idx, uint8_t *dist, int Q, int64_t N, int nbits, int k,
-                 int64_t idx_offset, uint32_t *cum, int tpq, hipStream_t st);
+int rank2_launch(const uint64_t *q, const void *img, int32_t *idx, uint16_t *rows16, uint8_t *dist, int Q, int64_t N, int nbits,
+                 int k, int64_t idx_offset, uint32_t *cum, int tpq, hipStream_t st);
 // the one-wave-per-query image exists for databases (shards) of at most this many rows
-constexpr int64_t kImg64MaxRows = 64 * 128;
+constexpr int64_t kImg64MaxRows = 64 * 64;
+// images of the windowed kernel exist for databases it can take at all (16-bit item numbers, <= 128 items per thread)
+constexpr int64_t kImg256MaxRows = 256 * 128;
+// prepared ranking blob: [first-generation column image][windowed kernel, 256 threads/query][.., 64 threads/query]
+static inline size_t old_image_bytes(int64_t N, int words) { return (size_t)ceil_div(N, kTopkThreads) * kTopkThreads * words * sizeof(uint64_t); }
+static inline size_t r2_off256(int64_t N, int words) { return (size_t)align_up((int64_t)old_image_bytes(N, words), 256); }
+static inline size_t r2_off64(int64_t N, int words)
+{
+    return r2_off256(N, words) + (N <= kImg256MaxRows ? (size_t)align_up((int64_t)rank2_image_bytes(N, words, 256), 256) : 0);
+}
 __device__ int g_topk_dbg = 0;   // WV_TOPK_DBG (timing experiments only): 1 = no list stores, 2 = skip phase 2, 4 = skip phase 1
 constexpr int kMaxBins = 130;  // nbits <= 128 (+1 bin for the padding value of ragged shard lists)
 
@@ -700,17 +709,16 @@ static int launch_topk(const uint64_t *q, const uint64_t *db, const uint64_t *db
     const int nbins = nbits + 1;
     const uint64_t *dbT = dbT_ready;
     if (const int tpq = rank2_tpq(Q, N, k)) {
-        // images: [256 threads per query][64 threads per query (only for N <= kImg64MaxRows)]
-        const size_t img256 = rank2_image_bytes(N, WORDS, 256);
-        const uint64_t *img = nullptr;
+        const void *img = nullptr;
         if (dbT_ready) {
-            img = tpq == 256 ? dbT_ready : (const uint64_t *)((const char *)dbT_ready + align_up((int64_t)img256, 256));
+            img = (const char *)dbT_ready + (tpq == 256 ? r2_off256(N, WORDS) : r2_off64(N, WORDS));
         } else {
             int rc0 = rank2_prepare(db, ws, N, WORDS, tpq, st);
             if (rc0) return rc0;
-            img = (const uint64_t *)ws;
+            img = ws;
         }
-        return rank2_launch(q, img, idx, dist, Q, N, nbits, k, idx_offset, cum, tpq, st);
+        const int rc2 = rank2_launch(q, img, idx, nullptr, dist, Q, N, nbits, k, idx_offset, cum, tpq, st);
+        if (rc2 <= 0) return rc2;                                // 1 = shape not covered after all: first-generation kernel
     }
     if (!dbT) {
         int rc0 = launch_transpose<WORDS>(db, (uint64_t *)ws, N, st);
@@ -737,17 +745,17 @@ static int launch_topk(const uint64_t *q, const uint64_t *db, const uint64_t *db
 
 size_t topk_prepared_bytes(int64_t N, int words)
 {
-    const size_t img256 = (size_t)ceil_div(N, kTopkThreads) * kTopkThreads * words * sizeof(uint64_t);
-    if (N > kImg64MaxRows) return img256;
-    return (size_t)align_up((int64_t)img256, 256) + rank2_image_bytes(N, words, 64);
+    size_t b = r2_off64(N, words);
+    if (N <= kImg64MaxRows) b += rank2_image_bytes(N, words, 64);
+    return b;
 }
 
 int topk_prepare(const uint64_t *db, void *dbT, int64_t N, int words, hipStream_t st)
 {
     int rc = words == 1 ? launch_transpose<1>(db, (uint64_t *)dbT, N, st) : launch_transpose<2>(db, (uint64_t *)dbT, N, st);
-    if (rc || N > kImg64MaxRows) return rc;
-    const size_t img256 = (size_t)ceil_div(N, kTopkThreads) * kTopkThreads * words * sizeof(uint64_t);
-    return rank2_prepare(db, (char *)dbT + align_up((int64_t)img256, 256), N, words, 64, st);
+    if (!rc && N <= kImg256MaxRows) rc = rank2_prepare(db, (char *)dbT + r2_off256(N, words), N, words, 256, st);
+    if (!rc && N <= kImg64MaxRows) rc = rank2_prepare(db, (char *)dbT + r2_off64(N, words), N, words, 64, st);
+    return rc;
 }
 
 }  // namespace wv
@@ -758,8 +766,8 @@ extern "C" size_t wv_hamming_topk_workspace_bytes(int Q, int64_t N, int words, i
 {
     (void)Q; (void)k;
     if (N <= 0 || words <= 0) return 0;
-    // one database image, for whichever thread count per query the call takes (the 64-thread one is never smaller)
-    return std::max((size_t)ceil_div(N, kTopkThreads) * kTopkThreads, (size_t)ceil_div(N, 64) * 64) * words * sizeof(uint64_t);
+    // one database image, for whichever kernel the call takes
+    return std::max(std::max(old_image_bytes(N, words), rank2_image_bytes(N, words, 256)), rank2_image_bytes(N, words, 64));
 }
 
 extern "C" int wv_hamming_topk(const uint64_t *q, const uint64_t *db, int32_t *idx, uint8_t *dist,
@@ -930,4 +938,50 @@ extern "C" int wv_hamming_topk_ex(const uint64_t *q, const uint64_t *db, const v
     }
     if (words == 1) return launch_topk<1>(q, db, dbT, idx, dist, Q, N, nbits, k, idx_offset, workspace, st, cum);
     return launch_topk<2>(q, db, dbT, idx, dist, Q, N, nbits, k, idx_offset, workspace, st, cum);
+}
+
+// ---------------------------------------------------------------------------------- sharded search, two steps
+static int shard_call(const char *what, const uint64_t *q, const uint64_t *db, const void *prepared, uint16_t *rows16,
+                      uint32_t *cum, int Q, int64_t N, int nbits, int k, void *workspace, size_t workspace_bytes, void *stream)
+{
+    const int words = (nbits + 63) / 64;
+    const int tpq = rank2_tpq(Q, N, std::max(k, 1));
+    if (!tpq) WV_FAIL(WV_ENOTSUP, "%s: shards of %lld rows / lists of %d entries are outside the windowed kernel "
+                                  "(rows <= 32768, 16-bit row numbers)", what, (long long)N, k);
+    hipStream_t st = (hipStream_t)stream;
+    const void *img = nullptr;
+    if (prepared) {
+        const char *base = (const char *)prepared + align_up((int64_t)dist_prepared_bytes(N, words), 256);
+        img = base + (tpq == 256 ? r2_off256(N, words) : r2_off64(N, words));
+    } else {
+        const size_t need = wv_hamming_topk_workspace_bytes(Q, N, words, k);
+        if (!workspace || workspace_bytes < need) WV_FAIL(WV_ENOMEM, "%s: workspace %zu < %zu bytes", what, workspace_bytes, need);
+        int rc0 = rank2_prepare(db, workspace, N, words, tpq, st);
+        if (rc0) return rc0;
+        img = workspace;
+    }
+    const int rc = rank2_launch(q, img, nullptr, rows16, nullptr, Q, N, nbits, k, 0, cum, tpq, st);
+    if (rc > 0) WV_FAIL(WV_ENOTSUP, "%s: shape outside the windowed kernel", what);
+    return rc;
+}
+
+extern "C" int wv_hamming_hist(const uint64_t *q, const uint64_t *db, const void *prepared, uint32_t *cum, int Q, int64_t N,
+                               int nbits, void *workspace, size_t workspace_bytes, void *stream)
+{
+    WV_REQUIRE(q && cum && (db || prepared), "hamming_hist: null buffer");
+    WV_REQUIRE(Q >= 0 && N >= 1, "hamming_hist: bad shape Q=%d N=%lld", Q, (long long)N);
+    WV_REQUIRE(nbits >= 1 && nbits <= 128, "hamming_hist: nbits=%d (supported: 1..128)", nbits);
+    if (Q == 0) return WV_OK;
+    return shard_call("hamming_hist", q, db, prepared, nullptr, cum, Q, N, nbits, 0, workspace, workspace_bytes, stream);
+}
+
+extern "C" int wv_hamming_topk_rows16(const uint64_t *q, const uint64_t *db, const void *prepared, uint16_t *rows, int Q,
+                                      int64_t N, int nbits, int k, void *workspace, size_t workspace_bytes, void *stream)
+{
+    WV_REQUIRE(q && rows && (db || prepared), "hamming_topk_rows16: null buffer");
+    WV_REQUIRE(Q >= 0 && N >= 1, "hamming_topk_rows16: bad shape Q=%d N=%lld", Q, (long long)N);
+    WV_REQUIRE(nbits >= 1 && nbits <= 128, "hamming_topk_rows16: nbits=%d (supported: 1..128)", nbits);
+    WV_REQUIRE(k >= 1 && k <= N, "hamming_topk_rows16: k=%d must be in [1, N=%lld]", k, (long long)N);
+    if (Q == 0) return WV_OK;
+    return shard_call("hamming_topk_rows16", q, db, prepared, rows, nullptr, Q, N, nbits, k, workspace, workspace_bytes, stream);
 }

@@ -179,6 +179,56 @@ def hamming_topk(q_packed, db, nbits, k, idx_offset=0, workspace=None, want_dist
     return idx, dist
 
 
+def _shard_db_args(db, words, nbits, what):
+    prepared = isinstance(db, PreparedDB)
+    N, dwords = (db.N, db.words) if prepared else db.shape
+    if dwords != words or words != _words(nbits):
+        raise ValueError(f"{what}: code widths do not match nbits")
+    return prepared, N
+
+
+SHARD_ROWS_MAX = 32768      # wv_hamming_hist / wv_hamming_topk_rows16 take shards up to this many rows
+
+
+def hamming_hist(q_packed, db, nbits, workspace=None):
+    """Cumulative distance histogram of every query over the rows of `db` (no list is built):
+    cum int32 [Q, nbits + 2], cum[q, b] = rows with distance < b.  First step of the sharded search."""
+    lib = _lib.require_gpu()
+    Q, words = q_packed.shape
+    prepared, N = _shard_db_args(db, words, nbits, "hamming_hist")
+    dev = q_packed.device
+    cum = torch.empty((Q, nbits + 2), dtype=torch.int32, device=dev)
+    ws, ws_bytes = None, 0
+    if not prepared:
+        ws_bytes = lib.wv_hamming_topk_workspace_bytes(Q, N, words, 1)
+        ws = (workspace or TopkWorkspace()).get(ws_bytes, dev)
+    with torch.cuda.device(dev):
+        rc = lib.wv_hamming_hist(_lib.ptr(q_packed), None if prepared else _lib.ptr(db), _lib.ptr(db.blob) if prepared else None,
+                                 _lib.ptr(cum), Q, N, nbits, _lib.ptr(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0),
+                                 _lib.stream_ptr())
+        _lib.check(rc, "wv_hamming_hist")
+    return cum
+
+
+def hamming_topk_rows16(q_packed, db, nbits, k, workspace=None):
+    """The k nearest rows of `db` per query, ascending (distance, row), as 16-bit LOCAL row numbers (int16 storage of
+    uint16 values [Q, k]): the wire format of the sharded search (topk_merge_cum)."""
+    lib = _lib.require_gpu()
+    Q, words = q_packed.shape
+    prepared, N = _shard_db_args(db, words, nbits, "hamming_topk_rows16")
+    dev = q_packed.device
+    rows = torch.empty((Q, k), dtype=torch.int16, device=dev)
+    ws = None
+    if not prepared:
+        ws = (workspace or TopkWorkspace()).get(lib.wv_hamming_topk_workspace_bytes(Q, N, words, k), dev)
+    with torch.cuda.device(dev):
+        rc = lib.wv_hamming_topk_rows16(_lib.ptr(q_packed), None if prepared else _lib.ptr(db),
+                                        _lib.ptr(db.blob) if prepared else None, _lib.ptr(rows), Q, N, nbits, k, _lib.ptr(ws),
+                                        ctypes.c_size_t(ws.numel() if ws is not None else 0), _lib.stream_ptr())
+        _lib.check(rc, "wv_hamming_topk_rows16")
+    return rows
+
+
 def topk_merge(idx_in, dist_in, k, nbits):
     """[G,Q,kin] per-shard lists (contiguous row shards in rank order) -> global [Q,k]."""
     lib = _lib.require_gpu()

@@ -97,13 +97,19 @@ def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, works
     k_local = min(kin, n_local)
     dev = q_local.device
     i = d = cum = None
-    if k_local > 0:
+    # Two-step form (shards the windowed kernel takes): histograms first -- cheap, no list -- so that every rank knows
+    # each query's global k-th distance BEFORE any list is built; the shard then ranks only the prefix that can matter
+    # (about k / world + ties entries instead of min(k, shard rows)) and writes it straight in the 16-bit wire format.
+    two_step = trim and 0 < n_local <= H.SHARD_ROWS_MAX and per <= H.SHARD_ROWS_MAX
+    if k_local > 0 and not two_step:
         if trim:
             # the compact exchange below ships histograms, not distance rows: do not even write them
             i, d, cum = H.hamming_topk(q_all, db_shard, nbits, k_local, idx_offset=lo, workspace=workspace,
                                        want_dist=per > 65536, want_cum=True)
         else:
             i, d = H.hamming_topk(q_all, db_shard, nbits, k_local, idx_offset=lo, workspace=workspace)
+    if two_step:
+        cum = H.hamming_hist(q_all, db_shard, nbits, workspace=workspace)
     send = kin
     need = None
     if trim:
@@ -124,12 +130,18 @@ def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, works
         # cumulative histogram of each query (a sorted list is fully described by it): 2 bytes per entry + 4*(nbits+2)
         # bytes per (query, shard) on the wire instead of 5 bytes per entry.  int16 storage, shipped as bytes (RCCL has
         # no 16-bit integer type).
-        loc_s = torch.zeros((world * Ql, send), dtype=torch.int16, device=dev)
-        if k_local > 0:
-            w = min(send, k_local)
-            loc_s[:, :w] = (i[:, :w] - lo).to(torch.int16)       # wraps for rows >= 32768; the kernel reads uint16
+        if two_step:
+            w = min(send, n_local)
+            loc_s = H.hamming_topk_rows16(q_all, db_shard, nbits, w, workspace=workspace)
+            if w < send:                                # a shard shorter than the prefix: pad (never read by the merge)
+                loc_s = torch.nn.functional.pad(loc_s, (0, send - w))
+        else:
+            loc_s = torch.zeros((world * Ql, send), dtype=torch.int16, device=dev)
+            if k_local > 0:
+                w = min(send, k_local)
+                loc_s[:, :w] = (i[:, :w] - lo).to(torch.int16)   # wraps for rows >= 32768; the kernel reads uint16
         loc_r = torch.empty_like(loc_s)
-        _all_to_all(loc_r.view(torch.uint8), loc_s.view(torch.uint8), group)
+        _all_to_all(loc_r.view(torch.uint8), loc_s.contiguous().view(torch.uint8), group)
         cum_r = torch.empty_like(cum)
         _all_to_all(cum_r, cum.contiguous(), group)
         # received layout: [shard g][my Ql queries][...]

@@ -179,6 +179,19 @@ int wv_hamming_topk_ex(const uint64_t *q, const uint64_t *db, const void *prepar
                        uint32_t *cum, int Q, int64_t N, int nbits, int k, int64_t idx_offset, void *workspace,
                        size_t workspace_bytes, void *stream);
 
+/* The two steps of a row-sharded search (wvhash/parallel.py; the role of faiss' shard search + host merge at
+ * get_knn.py:41-44) on one shard of at most 32,768 rows:
+ *   wv_hamming_hist        only the cumulative distance histogram of every query, cum uint32 [Q][nbits + 2] as above -- no
+ *                          list is built.  All-reduced over the shards it gives every rank the global k-th distance of every
+ *                          query, hence how long a list prefix each shard has to contribute (about k / shards + ties).
+ *   wv_hamming_topk_rows16 the k nearest rows of the shard per query in (distance, row) order as 16-bit LOCAL row numbers,
+ *                          uint16 [Q][k] -- the wire format wv_topk_merge_cum reads -- with k = that prefix length.
+ * Returns WV_ENOTSUP for shards outside the windowed kernel's range (the caller then uses wv_hamming_topk_ex). */
+int wv_hamming_hist(const uint64_t *q, const uint64_t *db, const void *prepared, uint32_t *cum, int Q, int64_t N, int nbits,
+                    void *workspace, size_t workspace_bytes, void *stream);
+int wv_hamming_topk_rows16(const uint64_t *q, const uint64_t *db, const void *prepared, uint16_t *rows, int Q, int64_t N,
+                           int nbits, int k, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Merge of G per-shard top-k lists (gathered with one all-gather) into the global top-k.
  * Replaces the host-side shard merge inside faiss.index_cpu_to_all_gpus(shards=True)
  *   (get_knn.py:41-44).  Lists must come from contiguous row shards in rank order, so that

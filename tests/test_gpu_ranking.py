@@ -241,7 +241,7 @@ def test_float_knn_seeded_against_oracle(metric, Q, N, D, k):
     if metric == "hamming":                      # sign(0)-style codes: not +-1 -> float IP path
         q, r = torch.sign(q), torch.sign(r)
         r[0, 0] = 0.0
-    idx, dist = get_knn(r, q, k, False, distance_metric=metric)
+    idx, dist = get_knn(r, q, k, False, with_faiss=False, distance_metric=metric)
     sd, si = ranking.knn_stable(r, q, k, metric)
     np.testing.assert_allclose(dist.cpu().numpy(), sd.numpy(), atol=3e-5 if metric != "hamming" else 0)
     # every returned value is the true value of the returned index, and the list is sorted
@@ -352,7 +352,7 @@ def test_float_knn_select_path_with_ties_across_the_threshold(metric):
     q = torch.randint(-2, 3, (Q, D), generator=g).float()
     r = torch.randint(-2, 3, (N, D), generator=g).float()
     r[N // 2:] = r[: N - N // 2].clone()
-    gi, gd = get_knn(r, q, k, False, distance_metric=metric)
+    gi, gd = get_knn(r, q, k, False, with_faiss=False, distance_metric=metric)
     sd, si = ranking.knn_stable(r, q, k, metric)
     assert torch.equal(gi.cpu().long(), si.long())
     assert torch.allclose(gd.cpu(), sd, rtol=1e-6, atol=1e-6)
@@ -490,3 +490,45 @@ def test_window_kernel_variants_and_multi_window_rankings(monkeypatch, variant, 
             assert (d[:, 1:] >= d[:, :-1]).all()
             same = d[:, 1:] == d[:, :-1]
             assert (idx[:, 1:][same] > idx[:, :-1][same]).all()
+
+
+@pytest.mark.parametrize("Q,N,nbits,k,G", [(37, 11000, 64, 3000, 8), (19, 999, 16, 999, 3), (4100, 5000, 64, 1200, 8),
+                                           (21, 20000, 128, 5000, 7), (9, 40, 32, 7, 5)])
+@pytest.mark.parametrize("prepared", [False, True])
+def test_two_step_sharded_search_on_one_gpu(Q, N, nbits, k, G, prepared):
+    """The steps every rank of wvhash/parallel.py runs, for G shards on one GPU: wv_hamming_hist per shard -> sum of the
+    histograms (the all-reduce) -> global k-th distance -> prefix length -> wv_hamming_topk_rows16 per shard ->
+    wv_topk_merge_cum.  Equal to the unsharded ranking; histograms and 16-bit lists equal the oracle's."""
+    q, r = (synth.random_codes(Q, N, nbits, seed=N + G) if Q > 100 else _spread_codes(Q, N, nbits, seed=N + G))
+    qp, rp = H.pack_codes(q.cuda()), H.pack_codes(r.cuda())
+    full_idx, full_d = H.hamming_topk(qp, rp, nbits, k)
+    per = (N + G - 1) // G
+    shards = []
+    for g in range(G):
+        lo, hi = min(N, g * per), min(N, (g + 1) * per)
+        rows = rp[lo:hi].contiguous()
+        shards.append((lo, hi, (H.PreparedDB(rows, nbits) if prepared else rows) if hi > lo else None))
+    cums = []
+    for lo, hi, db in shards:
+        cum = H.hamming_hist(qp, db, nbits) if db is not None else torch.zeros((Q, nbits + 2), dtype=torch.int32, device="cuda")
+        if db is not None:
+            dm = ranking.hamming_matrix_u8(q[:16], r[lo:hi])
+            ref = torch.stack([(dm < b).sum(1) for b in range(nbits + 2)], dim=1)
+            assert torch.equal(cum[:16].cpu().long(), ref)
+        cums.append(cum)
+    cum = torch.stack(cums)
+    T = (cum.sum(0)[:, 1:] >= k).int().argmax(dim=1)
+    need = int(torch.gather(cum, 2, (T + 1).view(1, Q, 1).expand(G, Q, 1).long()).max().item())
+    send = max(1, min(min(k, per), need))
+    lists = []
+    for lo, hi, db in shards:
+        loc = torch.zeros((Q, send), dtype=torch.int16, device="cuda")
+        w = min(send, hi - lo)
+        if w > 0:
+            loc[:, :w] = H.hamming_topk_rows16(qp, db, nbits, w)
+            ref_i, _ = ranking.hamming_topk_stable(q[:16], r[lo:hi], w)
+            assert torch.equal((loc[:16, :w].cpu().long() & 0xffff), ref_i)
+        lists.append(loc)
+    mi, md = H.topk_merge_cum(torch.stack(lists), cum, per, k, nbits)
+    assert torch.equal(mi, full_idx) and torch.equal(md, full_d)
+    assert send < min(k, per) or G == 1 or k >= N            # the trimmed prefix really is shorter than the full list

@@ -44,6 +44,18 @@ def _fake_topk(q_packed, db, nbits, k, idx_offset=0, workspace=None, want_dist=T
     return (idx + idx_offset).int(), d.to(torch.uint8), cum
 
 
+def _fake_hist(q_packed, db, nbits, workspace=None):
+    from oracle import ranking
+    dm = ranking.hamming_matrix_u8(_unpack(q_packed, nbits), _unpack(db, nbits))
+    return torch.stack([(dm < b).sum(1) for b in range(nbits + 2)], dim=1).int()
+
+
+def _fake_rows16(q_packed, db, nbits, k, workspace=None):
+    from oracle import ranking
+    idx, _ = ranking.hamming_topk_stable(_unpack(q_packed, nbits), _unpack(db, nbits), k)
+    return idx.to(torch.int16)                                     # local rows (< 32768 in these tests)
+
+
 def _fake_merge(idx_in, dist_in, k, nbits):
     G, Q, kin = idx_in.shape
     key = dist_in.permute(1, 0, 2).reshape(Q, G * kin).long()      # (shard, position) order per query
@@ -71,6 +83,7 @@ def _worker(rank, world, port, cases, nbits, ql, out_dir):
     from wvhash import parallel, synth
     from wvhash.engine import hamming as H
     H.hamming_topk, H.topk_merge, H.topk_merge_cum = _fake_topk, _fake_merge, _fake_merge_cum   # CPU stand-ins for the kernels
+    H.hamming_hist, H.hamming_topk_rows16 = _fake_hist, _fake_rows16
     out = {}
     for n_db, k in cases:
         q_all, r = synth.random_codes(world * ql, n_db, nbits, seed=3)
@@ -79,6 +92,11 @@ def _worker(rank, world, port, cases, nbits, ql, out_dir):
             idx, d = parallel.sharded_hamming_topk(_pack(q_all[rank * ql:(rank + 1) * ql]), _pack(r[lo:hi]), nbits,
                                                    k, n_db, trim=trim)
             out[(n_db, k, trim)] = (idx, d)
+        # the one-step trimmed form (what shards beyond the two-step kernels' range take) gives the same lists
+        keep, H.SHARD_ROWS_MAX = H.SHARD_ROWS_MAX, 0
+        idx1, d1 = parallel.sharded_hamming_topk(_pack(q_all[rank * ql:(rank + 1) * ql]), _pack(r[lo:hi]), nbits, k, n_db)
+        H.SHARD_ROWS_MAX = keep
+        assert torch.equal(idx1, out[(n_db, k, True)][0]) and torch.equal(d1, out[(n_db, k, True)][1])
         # hinted exchange (no host read): a generous hint is exact and verifies, a hint of 1 entry is flagged
         shard, kin = _pack(r[lo:hi]), min(k, parallel.shard_bounds(n_db, world, rank)[2])
         qs = _pack(q_all[rank * ql:(rank + 1) * ql])

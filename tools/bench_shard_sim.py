@@ -23,12 +23,15 @@ for world in (1, 2, 4, 8):
     kl = min(K, per)
     t_local = timeit(lambda: H.hamming_topk(qp, prep, 64, kl, want_dist=False, want_cum=True))
     send = min(kl, int(K / world * 1.6) + 64)
+    t_hist = timeit(lambda: H.hamming_hist(qp, prep, 64))
+    t_rows = timeit(lambda: H.hamming_topk_rows16(qp, prep, 64, send))
     # what a rank receives for ITS QL queries: per shard the list prefix (16-bit local rows) + the cumulative histogram
     _, _, cum = H.hamming_topk(qp[:QL], prep, 64, kl, want_dist=False, want_cum=True)
     loc = torch.randint(0, per, (world, QL, send), dtype=torch.int32, device="cuda").to(torch.int16)
     cums = cum.unsqueeze(0).expand(world, QL, 66).contiguous()
     t_merge = timeit(lambda: H.topk_merge_cum(loc, cums, per, min(K, world * send), 64)) if world > 1 else 0.0
     mb = world * QL * (send * 2 + 66 * 4) / 1e6
-    print(f"world={world}: local rank of {world*QL} queries vs {per} rows (k'={kl}): {t_local*1e3:.0f} us | "
+    print(f"world={world}: one-step local rank of {world*QL} queries vs {per} rows (k'={kl}): {t_local*1e3:.0f} us | "
+          f"two-step: histograms {t_hist*1e3:.0f} us + {send}-entry 16-bit lists {t_rows*1e3:.0f} us | "
           f"compact merge {world} x {send}: {t_merge*1e3:.0f} us | sent per rank ~{mb:.0f} MB "
           f"(int32+u8 lists: {world * QL * send * 5 / 1e6:.0f} MB)", flush=True)

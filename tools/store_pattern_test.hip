@@ -115,6 +115,45 @@ __global__ __launch_bounds__(256) void kH(float *out, float v, int planes)
         for (int i = lane; i < H * W / 4; i += 64) o[i] = make_float4(v, v, v, v + i);
     }
 }
+// M: the sliding kernel's consumer with quad-transposed stores: thread = column, but each lane of a quad writes ONE
+// row of the quad's 4 columns as a float4 (row y0 + 4g + (t & 3)), 4 bands, 16-row chunks
+template <int NTH>
+__global__ __launch_bounds__(NTH) void kM(float *out, float v, int planes)
+{
+    const size_t band = (size_t)H * W;
+    const int t = threadIdx.x;
+    if (t >= W) return;
+    const int j = t & 3, c0 = t & ~3;
+    for (int p = blockIdx.x; p < planes; p += gridDim.x) {
+        float *o = out + (size_t)p * 4 * band + c0;
+        for (int y0 = 0; y0 < H; y0 += 16) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int bd = 0; bd < 4; ++bd)
+                    *reinterpret_cast<float4 *>(o + bd * band + (size_t)(y0 + 4 * g + j) * W) = make_float4(v, v + g, v + bd, v + j);
+        }
+    }
+}
+// N: like M but a lane owns 4 consecutive rows' worth of ONE row segment of 16 columns?  -> thread = (row-in-group, 16-B column group):
+// 64 lanes = 1 row x 56 float4 (one full 896-B row per wave instruction), waves take rows round-robin
+__global__ __launch_bounds__(256) void kN(float *out, float v, int planes)
+{
+    const size_t band = (size_t)H * W;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane >= W / 4) return;
+    for (int p = blockIdx.x; p < planes; p += gridDim.x) {
+        float *o = out + (size_t)p * 4 * band + 4 * lane;
+        for (int y0 = 0; y0 < H; y0 += 16) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int bd = 0; bd < 4; ++bd)
+                    *reinterpret_cast<float4 *>(o + bd * band + (size_t)(y0 + 4 * g + wv) * W) = make_float4(v, v + g, v + bd, v);
+        }
+    }
+}
+
 int main()
 {
     const int B = 2048;
@@ -123,7 +162,7 @@ int main()
     CK(hipMalloc(&out, n * 4));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int which = 0; which < 12; ++which) {
+    for (int which = 0; which < 16; ++which) {
         float best = 1e9f;
         for (int rep = 0; rep < 5; ++rep) {
             CK(hipEventRecord(e0));
@@ -139,6 +178,10 @@ int main()
             if (which == 9) hipLaunchKernelGGL((kF<0, 256>), dim3(1024), dim3(256), 0, 0, out, 1.0f, 3 * B);
             if (which == 10) hipLaunchKernelGGL(kG, dim3(1024), dim3(256), 0, 0, out, 1.0f, 3 * B);
             if (which == 11) hipLaunchKernelGGL(kH, dim3(1024), dim3(256), 0, 0, out, 1.0f, 3 * B);
+            if (which == 12) hipLaunchKernelGGL((kM<256>), dim3(512), dim3(256), 0, 0, out, 1.0f, 3 * B);
+            if (which == 13) hipLaunchKernelGGL((kM<256>), dim3(1024), dim3(256), 0, 0, out, 1.0f, 3 * B);
+            if (which == 14) hipLaunchKernelGGL(kN, dim3(512), dim3(256), 0, 0, out, 1.0f, 3 * B);
+            if (which == 15) hipLaunchKernelGGL(kN, dim3(1024), dim3(256), 0, 0, out, 1.0f, 3 * B);
             CK(hipEventRecord(e1));
             CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
