@@ -779,6 +779,17 @@ extern "C" size_t wv_band_attn_pool_workspace_bytes(const wv_head_params *p, int
     return carve(p, B, nullptr).bytes;
 }
 
+extern "C" int wv_band_attn_qproj(const wv_head_params *p, float *q_proj_out, void *stream)
+{
+    int rc = check_head(p, 1);
+    if (rc) return rc;
+    WV_REQUIRE(q_proj_out, "band_attn_qproj: null buffer");
+    hipLaunchKernelGGL(k_qproj, dim3((unsigned)ceil_div(p->num_queries * p->embed_dim, 4)), dim3(256), 0, (hipStream_t)stream,
+                       p->q_eff, p->in_proj_w, p->in_proj_b, q_proj_out, p->num_queries, p->embed_dim);
+    WV_CHECK_LAUNCH("k_qproj");
+    return WV_OK;
+}
+
 extern "C" int wv_band_attn_pool(const wv_head_params *p, const float *feats, int B, float *out,
                                  void *workspace, size_t workspace_bytes, void *stream)
 {
@@ -794,15 +805,19 @@ extern "C" int wv_band_attn_pool(const wv_head_params *p, const float *feats, in
     const int E = p->embed_dim, Nq = p->num_queries, S = p->num_tokens, rows = B * Nq;
     HeadWs w = carve(p, B, workspace);
 
-    // Q projection (batch-invariant): Qp = q_eff @ Wq^T + bq
-    hipLaunchKernelGGL(k_qproj, dim3((unsigned)ceil_div(Nq * E, 4)), dim3(256), 0, st, p->q_eff, p->in_proj_w,
-                       p->in_proj_b, w.Qp, Nq, E);
+    // Q projection (batch-invariant): Qp = q_eff @ Wq^T + bq -- taken from the caller when it was made ahead of time
+    const float *Qp = p->q_proj;
+    if (!Qp) {
+        hipLaunchKernelGGL(k_qproj, dim3((unsigned)ceil_div(Nq * E, 4)), dim3(256), 0, st, p->q_eff, p->in_proj_w,
+                           p->in_proj_b, w.Qp, Nq, E);
+        Qp = w.Qp;
+    }
     // K | V projection of all S*B tokens: rows E..3E of in_proj_weight
     launch_gemm<EPI_NONE>(feats, p->in_proj_w + (size_t)E * E, p->in_proj_b + E, nullptr, 1, w.KV, S * B, 2 * E, E, st);
     const size_t sm = ((size_t)S * (2 * E + 4) + (size_t)Nq * E + (size_t)Nq * p->num_heads * S) * sizeof(float);
     if (sm > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn_core), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    hipLaunchKernelGGL(k_attn_core, dim3(B), dim3(256), sm, st, w.Qp, w.KV, w.ctx, B, E, p->num_heads, Nq, S);
+    hipLaunchKernelGGL(k_attn_core, dim3(B), dim3(256), sm, st, Qp, w.KV, w.ctx, B, E, p->num_heads, Nq, S);
     // x1 = q_eff + ctx @ Wo^T + bo ; x1n = LN1(x1)
     launch_gemm<EPI_ADD_BCAST>(w.ctx, p->attn_out_w, p->attn_out_b, p->q_eff, Nq, w.x1, rows, E, E, st);
     launch_layernorm(w.x1, p->norm1_w, p->norm1_b, w.x1n, (int64_t)rows, E, p->ln_eps, 1, st);

@@ -80,7 +80,9 @@ __host__ __device__ inline size_t rank2_lds_bytes_per_query(int k)
     size_t b = (size_t)kWinRows * (TPQ / 2) * 4;                 // table
     b += ((size_t)(k + TPQ) * 2 + 15) / 16 * 16;                 // stage
     b += (size_t)(kMaxBins2 + 1 + kWinBins + 4 + 3) / 4 * 4 * 4; // gbase, tot, misc
-    return (b + 15) / 16 * 16;
+    b = (b + 15) / 16 * 16;
+    const size_t hist = (size_t)(kMaxBins2 + 1) * 17 * 4;        // histogram-only mode: [bins + 1][16] dwords + totals
+    return b > hist ? b : (hist + 15) / 16 * 16;
 }
 
 // One pass over the database image: distances of QB queries -> bytes in registers (dc[qq][i/4] byte i%4 = item i of this
@@ -135,6 +137,59 @@ __device__ __forceinline__ void rank2_distances(const uint4 *__restrict__ img, c
             }
         }
     }
+}
+
+// Histogram only (first step of the sharded search): ONE count pass over all bins.  No per-thread cells are needed when
+// nothing is placed, so 8 threads share a cell (cell = (bin, t & 31), 16-bit): nbins + 1 rows of 64 bytes.
+template <int TPQ, int NC>
+__device__ __forceinline__ void rank2_hist_only(const uint32_t (&dc)[NC], int64_t N, int C, int nbins,
+                                                uint32_t *__restrict__ cum_out, uint8_t *lds_raw, int t)
+{
+    uint32_t *table = reinterpret_cast<uint32_t *>(lds_raw);     // [nbins + 1][16] dwords (the window table's space: 8.3 KB of 16.9)
+    uint32_t *tot = table + (kMaxBins2 + 1) * 16;                // [kMaxBins2 + 1]
+    for (int i = t; i < (nbins + 1) * 16; i += TPQ) table[i] = 0;
+    group_sync<TPQ>();
+    const uint32_t c = (uint32_t)(t & 31);
+    const uint32_t cell_addr = (c >> 1) * 4u, cell_inc = 1u << (16 * (c & 1));
+    char *tbl = reinterpret_cast<char *>(table);
+#pragma unroll
+    for (int bw = 0; bw < NC; bw += 2) {
+        if (bw * 4 < C) {                                         // uniform
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (bw + (j >> 2) < NC) {
+                    const uint32_t d = (dc[bw + (j >> 2)] >> (8 * (j & 3))) & 0xffu;
+                    const uint32_t b = min(d, (uint32_t)nbins);   // 255 (no item) -> the dummy row
+                    __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(tbl + b * 64 + cell_addr), cell_inc,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    group_sync<TPQ>();
+    for (int b = t; b < nbins; b += TPQ) {                        // thread b sums row b
+        const uint4 *row = reinterpret_cast<const uint4 *>(table + b * 16);
+        uint32_t s = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 v = row[i];
+            s += (v.x & 0xffffu) + (v.x >> 16) + (v.y & 0xffffu) + (v.y >> 16) + (v.z & 0xffffu) + (v.z >> 16) +
+                 (v.w & 0xffffu) + (v.w >> 16);
+        }
+        tot[b] = s;
+    }
+    group_sync<TPQ>();
+    if (t < 64) {                                                 // exclusive scan over the bins: 3 bins per lane >= 130
+        const int b0 = 3 * t;
+        const uint32_t t0 = b0 < nbins ? tot[b0] : 0u, t1 = b0 + 1 < nbins ? tot[b0 + 1] : 0u, t2 = b0 + 2 < nbins ? tot[b0 + 2] : 0u;
+        const uint32_t incl = wave_incl_scan_u32(t0 + t1 + t2), excl = incl - (t0 + t1 + t2);
+        if (b0 <= nbins) cum_out[b0] = excl;
+        if (b0 + 1 <= nbins) cum_out[b0 + 1] = excl + t0;
+        if (b0 + 2 <= nbins) cum_out[b0 + 2] = excl + t0 + t1;
+    }
+    group_sync<TPQ>();
+    (void)N;
 }
 
 // Ranks ONE query from its cached distances.  Ends with a group barrier: the LDS region may be reused at once.
@@ -422,7 +477,9 @@ __global__ __launch_bounds__(256, rank2_min_waves(NC, QB)) void k_rank_window(co
 #pragma unroll
     for (int qq = 0; qq < QB; ++qq) {
         const int qi = q0 + qq;
-        if (qi < Q)                                              // uniform over the group (and over the workgroup when TPQ = 256)
+        if (qi < Q && k == 0)                                    // histogram only
+            rank2_hist_only<TPQ, NC>(dc[qq], N, C, nbins, cum + (int64_t)qi * (nbins + 1), lds, t);
+        else if (qi < Q)                                         // uniform over the group (and over the workgroup when TPQ = 256)
             rank2_one_query<TPQ, NC>(dc[qq], dmin[qq], N, C, nbins, k, idx_offset, idx ? idx + (int64_t)qi * k : nullptr,
                                      rows16 ? rows16 + (int64_t)qi * k : nullptr, dist ? dist + (int64_t)qi * k : nullptr,
                                      cum ? cum + (int64_t)qi * (nbins + 1) : nullptr, lds, t);

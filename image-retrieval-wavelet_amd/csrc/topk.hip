@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256) void k_merge_sorted(const int32_t *__restrict_
 // AP over a ranked list (accuracy_calculator.py:222-229): hits at 1-based ranks r_1 < r_2 < ...
 // give AP = mean_j (j / r_j); relevance = labels share a bit (label_comparison_fn :31-37).
 template <int LW>
-__global__ __launch_bounds__(256) void k_map_at_k(const int32_t *__restrict__ idx, int k,
+__global__ __launch_bounds__(256) void k_map_at_k(const int32_t *__restrict__ idx, int64_t ld, int k,
                                                   const uint64_t *__restrict__ qlab,
                                                   const uint64_t *__restrict__ dblab, int lwords,
                                                   float *__restrict__ ap, int32_t *__restrict__ nrel)
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void k_map_at_k(const int32_t *__restrict__ id
     __shared__ uint32_t wave_cnt[4];
     __shared__ double wave_sum[4];
     const int qi = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wv = wave_id();
-    const int32_t *list = idx + (int64_t)qi * k;
+    const int32_t *list = idx + (int64_t)qi * ld;
     const int lw = LW > 0 ? LW : lwords;
     uint64_t ql[LW > 0 ? LW : 1];
     if constexpr (LW > 0) {
@@ -888,21 +888,27 @@ extern "C" int wv_rank_from_dist(const uint8_t *dist_matrix, int64_t ld_dist, in
     return WV_OK;
 }
 
-extern "C" int wv_map_at_k(const int32_t *idx, int Q, int k, const uint64_t *qlab,
-                           const uint64_t *dblab, int lwords, float *ap, int32_t *nrel, void *stream)
+extern "C" int wv_map_at_k_ld(const int32_t *idx, int64_t ld, int Q, int k, const uint64_t *qlab,
+                              const uint64_t *dblab, int lwords, float *ap, int32_t *nrel, void *stream)
 {
     WV_REQUIRE(idx && qlab && dblab && ap, "map_at_k: null buffer");
-    WV_REQUIRE(Q >= 0 && k >= 1 && lwords >= 1, "map_at_k: bad shape Q=%d k=%d lwords=%d", Q, k, lwords);
+    WV_REQUIRE(Q >= 0 && k >= 1 && lwords >= 1 && ld >= k, "map_at_k: bad shape Q=%d k=%d ld=%lld lwords=%d", Q, k, (long long)ld, lwords);
     if (Q == 0) return WV_OK;
     hipStream_t st = (hipStream_t)stream;
     if (lwords == 1)
-        hipLaunchKernelGGL((k_map_at_k<1>), dim3(Q), dim3(256), 0, st, idx, k, qlab, dblab, lwords, ap, nrel);
+        hipLaunchKernelGGL((k_map_at_k<1>), dim3(Q), dim3(256), 0, st, idx, ld, k, qlab, dblab, lwords, ap, nrel);
     else if (lwords == 2)
-        hipLaunchKernelGGL((k_map_at_k<2>), dim3(Q), dim3(256), 0, st, idx, k, qlab, dblab, lwords, ap, nrel);
+        hipLaunchKernelGGL((k_map_at_k<2>), dim3(Q), dim3(256), 0, st, idx, ld, k, qlab, dblab, lwords, ap, nrel);
     else
-        hipLaunchKernelGGL((k_map_at_k<0>), dim3(Q), dim3(256), 0, st, idx, k, qlab, dblab, lwords, ap, nrel);
+        hipLaunchKernelGGL((k_map_at_k<0>), dim3(Q), dim3(256), 0, st, idx, ld, k, qlab, dblab, lwords, ap, nrel);
     WV_CHECK_LAUNCH("k_map_at_k");
     return WV_OK;
+}
+
+extern "C" int wv_map_at_k(const int32_t *idx, int Q, int k, const uint64_t *qlab,
+                           const uint64_t *dblab, int lwords, float *ap, int32_t *nrel, void *stream)
+{
+    return wv_map_at_k_ld(idx, k, Q, k, qlab, dblab, lwords, ap, nrel, stream);
 }
 
 extern "C" int wv_hit_prefix(const int32_t *idx, int Q, int k, const uint64_t *qlab, const uint64_t *dblab,

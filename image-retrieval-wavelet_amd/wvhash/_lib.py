@@ -38,6 +38,7 @@ class HeadParams(ctypes.Structure):
         ("out_w", ctypes.c_void_p), ("out_b", ctypes.c_void_p),
         ("norm2_w", ctypes.c_void_p), ("norm2_b", ctypes.c_void_p),
         ("ln_eps", ctypes.c_float),
+        ("q_proj", ctypes.c_void_p),
     ]
 
 
@@ -75,11 +76,13 @@ SIGNATURES = {
     "wv_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
     "wv_rank_from_dist": (_i, [_vp, _i64, _i, _i64, _i, _vp, _vp, _i, _vp]),
     "wv_map_at_k": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "wv_map_at_k_ld": (_i, [_vp, _i64, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "wv_topk_merge_cum": (_i, [_vp, _vp, _i, _i, _i, _i64, _vp, _vp, _i, _i, _vp]),
     "wv_hit_prefix": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "wv_knn_float_workspace_bytes": (_sz, [_i, _i64, _i, _i]),
     "wv_knn_float": (_i, [_vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "wv_band_attn_pool_workspace_bytes": (_sz, [ctypes.POINTER(HeadParams), _i]),
+    "wv_band_attn_qproj": (_i, [ctypes.POINTER(HeadParams), _vp, _vp]),
     "wv_band_attn_pool": (_i, [ctypes.POINTER(HeadParams), _vp, _i, _vp, _vp, _sz, _vp]),
     "wv_hash_tail": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),
 }

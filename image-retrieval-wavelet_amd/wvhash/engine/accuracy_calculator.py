@@ -18,11 +18,58 @@ import torch
 
 from .. import _lib
 from . import hamming as H
-from .get_knn import get_knn, _to_gpu
+from .get_knn import get_knn, _to_gpu, _is_pm1
 
 LOGGER = logging.getLogger("RETRIEVAL")
 
 _RECALL_KS = (1, 2, 4, 8, 10, 16, 20, 30, 32, 100, 1000)
+
+
+class RankCache(object):
+    """Packed codes, packed labels and ranked lists of ONE (query, reference) embedding pair, shared by the calculators
+    of an evaluate_multi_k run: the database is packed once and ranked once at the largest k asked for; every smaller k
+    reads a prefix (the reference re-runs its whole per-query loop for every k, main/engine/evaluate.py:226-243).
+    Entries are keyed by tensor identity (storage pointer, shape, version counter): new embeddings invalidate them."""
+
+    def __init__(self, kmax_hint=0):
+        self.kmax_hint = int(kmax_hint)
+        self._codes, self._labels, self._lists = {}, {}, None
+
+    @staticmethod
+    def _key(t):
+        return (t.data_ptr(), tuple(t.shape), t.dtype, t._version)
+
+    def packed_codes(self, x):
+        key = self._key(x)
+        if key not in self._codes:
+            self._codes = {k_: v for k_, v in self._codes.items() if len(self._codes) < 4}
+            self._codes[key] = H.pack_codes(x)
+        return self._codes[key]
+
+    def packed_labels(self, query_labels, reference_labels):
+        key = (self._key(query_labels), self._key(reference_labels))
+        if key not in self._labels:
+            self._labels = {key: CustomCalculator._packed_labels(query_labels, reference_labels)}
+        return self._labels[key]
+
+    def lists(self, query, reference, k):
+        """int32 [Q, >= k] ranked lists (ascending distance, then index); only the first k columns are meaningful to the caller."""
+        key = (self._key(query), self._key(reference))
+        if self._lists is None or self._lists[0] != key or self._lists[1].shape[1] < k:
+            kk = min(reference.shape[0], max(k, self.kmax_hint))
+            idx, dist = H.hamming_topk(self.packed_codes(query), self.packed_codes(reference), reference.shape[1], kk)
+            self._lists = (key, idx, dist)
+        return self._lists[1]
+
+    def knn(self, reference, query, num_k, same_source):
+        """get_knn(..., distance_metric='hamming') from the cached ranking: (indices int64, inner products fp32)."""
+        num_k += int(same_source)
+        if num_k > reference.shape[0]:
+            raise RuntimeError(f"selected index k out of range (k={num_k}, references={reference.shape[0]})")
+        idx = self.lists(query, reference, num_k)[:, :num_k]
+        ip = float(reference.shape[1]) - 2.0 * self._lists[2][:, :num_k].float()
+        first = int(same_source)
+        return idx[:, first:].long(), ip[:, first:]
 
 
 class CustomCalculator(object):
@@ -41,6 +88,7 @@ class CustomCalculator(object):
         self.with_faiss = with_faiss
         self.pr_rc_path, self.last_pr_rc = kwargs.pop("pr_rc_path", "pr_rc.csv"), None
         self.distance_metric = distance_metric
+        self.rank_cache = kwargs.pop("rank_cache", None)          # shared by the calculators of evaluate_multi_k
         # the reference pins the calculator to the CPU (main/engine/evaluate.py:76-81); here the
         # ranking stage lives on the GPU whatever `device` says
         self.requested_device = device
@@ -128,6 +176,9 @@ class CustomCalculator(object):
         return self.per_bit_balance(reference).min().item()
 
     def _ranked_lists(self, query, reference, topk):
+        """int32 [Q, >= topk]: the first topk columns are the ranked list (a shared RankCache may hold longer lists)."""
+        if self.rank_cache is not None:
+            return self.rank_cache.lists(query, reference, topk)
         nbits = reference.shape[1]
         return H.hamming_topk(H.pack_codes(query), H.pack_codes(reference), nbits, topk, want_dist=False)[0]
 
@@ -139,8 +190,10 @@ class CustomCalculator(object):
             reference_labels = (reference_labels.unsqueeze(1) == classes).float()
         return H.pack_labels(query_labels), H.pack_labels(reference_labels)
 
-    def _average_precisions(self, idx, query_labels, reference_labels):
-        return H.map_at_k(idx, *self._packed_labels(query_labels, reference_labels))
+    def _average_precisions(self, idx, query_labels, reference_labels, k=None):
+        packed = (self.rank_cache.packed_labels(query_labels, reference_labels) if self.rank_cache is not None
+                  else self._packed_labels(query_labels, reference_labels))
+        return H.map_at_k(idx, *packed, k=k)
 
     def _hits(self, idx, query_labels, reference_labels):
         """Running hit counts along the ranked lists, int32 [Q, k] (wv_hit_prefix)."""
@@ -160,7 +213,7 @@ class CustomCalculator(object):
         if num_query == 0:
             raise ZeroDivisionError("calculate_maphashing: no queries")
         idx = self._ranked_lists(query, reference, topk)
-        ap, _ = self._average_precisions(idx, query_labels, reference_labels)
+        ap, _ = self._average_precisions(idx, query_labels, reference_labels, k=topk)
         result = ap.double().sum().item() / num_query
         if return_per_query:
             return result, ap
@@ -218,7 +271,8 @@ class CustomCalculator(object):
         queries that are not lone and have a relevant item; writes the curve, returns 0."""
         query, reference = _to_gpu(query), _to_gpu(reference)
         query_labels, reference_labels = _to_gpu(query_labels), _to_gpu(reference_labels)
-        hits = self._hits(self._ranked_lists(query, reference, reference.shape[0]), query_labels, reference_labels)
+        hits = self._hits(self._ranked_lists(query, reference, reference.shape[0])[:, :reference.shape[0]], query_labels,
+                          reference_labels)
         ok = hits[:, -1] > 0
         if not_lone_query_mask is not None:
             ok &= not_lone_query_mask
@@ -269,10 +323,14 @@ class CustomCalculator(object):
             self_count = int(embeddings_come_from_same_source)
             not_lone_query_mask = (match_counts - self_count) > 0
             num_k = self.determine_k(match_counts, len(reference), embeddings_come_from_same_source)
-            knn_indices, knn_distances = get_knn(
-                reference, query, num_k, embeddings_come_from_same_source,
-                with_faiss=self.with_faiss, distance_metric=self.distance_metric,
-            )
+            if (self.rank_cache is not None and self.distance_metric == "hamming" and reference.shape[1] <= 128
+                    and _is_pm1(reference) and _is_pm1(query)):
+                knn_indices, knn_distances = self.rank_cache.knn(reference, query, num_k, embeddings_come_from_same_source)
+            else:
+                knn_indices, knn_distances = get_knn(
+                    reference, query, num_k, embeddings_come_from_same_source,
+                    with_faiss=self.with_faiss, distance_metric=self.distance_metric,
+                )
             if not bool(not_lone_query_mask.any()):
                 LOGGER.warning("None of the query labels are in the reference set.")
             kwargs["knn_indices"] = knn_indices

@@ -214,7 +214,10 @@ def evaluate(net, train_dataset=None, val_dataset=None, test_dataset=None, epoch
 @_preserve_rng
 def evaluate_multi_k(net, train_dataset=None, val_dataset=None, test_dataset=None, epoch=None, custom_eval=None,
                      k_list=(5000,), **kwargs):
-    """Embeds once, ranks once per k.  Returns {k: {split: {metric: value}}} like the reference."""
+    """Embeds once and ranks once: the calculators of all k share a RankCache -- packed codes, packed labels and the
+    ranked lists at the largest k; every smaller k is a prefix.  Returns {k: {split: {metric: value}}} like the
+    reference, which re-runs the whole ranking per k (main/engine/evaluate.py:226-243)."""
+    from .accuracy_calculator import RankCache
     dataset_dict, splits_to_eval = _build_dataset_dict_and_splits(train_dataset, val_dataset, test_dataset, custom_eval)
     k_list = list(k_list)
     tester = get_tester(k=k_list[0], **kwargs)
@@ -222,9 +225,11 @@ def evaluate_multi_k(net, train_dataset=None, val_dataset=None, test_dataset=Non
     splits_to_eval, needed = tester.get_splits_to_compute_embeddings(dataset_dict, splits_to_eval)
     LOGGER.info(f"Computing embeddings once, reused for k in {k_list}")
     emb = tester.get_all_embeddings_for_all_splits(dataset_dict, net, None, needed)
+    ints = [k for k in k_list if isinstance(k, int)]
+    cache = RankCache(kmax_hint=max(ints) if ints else 0)
     results_by_k = {}
     for k in k_list:
-        tester.accuracy_calculator = get_tester(k=k, **kwargs).accuracy_calculator
+        tester.accuracy_calculator = get_tester(k=k, rank_cache=cache, **kwargs).accuracy_calculator
         all_accuracies = defaultdict(dict)
         for query_split_name, reference_split_names in splits_to_eval:
             all_accuracies[query_split_name]["epoch"] = f"{epoch}"

@@ -274,20 +274,25 @@ def rank_from_dist(dist_matrix, nbits, k):
     return idx, dist
 
 
-def map_at_k(idx, qlab_packed, dblab_packed):
-    """Average precision per query over its ranked list -> (ap float32 [Q], nrel int32 [Q])."""
+def map_at_k(idx, qlab_packed, dblab_packed, k=None):
+    """Average precision per query over (the first k entries of) its ranked list -> (ap float32 [Q], nrel int32 [Q])."""
     lib = _lib.require_gpu()
-    Q, k = idx.shape
+    Q, kfull = idx.shape
+    k = kfull if k is None else int(k)
+    if not 1 <= k <= kfull:
+        raise ValueError(f"map_at_k: k={k} outside the lists' length {kfull}")
     lw = qlab_packed.shape[1]
     if dblab_packed.shape[1] != lw:
         raise ValueError("map_at_k: label widths differ")
+    if idx.stride(1) != 1:
+        idx = idx.contiguous()
     ap = torch.empty(Q, dtype=torch.float32, device=idx.device)
     nrel = torch.empty(Q, dtype=torch.int32, device=idx.device)
     if Q:
         with torch.cuda.device(idx.device):
-            rc = lib.wv_map_at_k(_lib.ptr(idx.contiguous()), Q, k, _lib.ptr(qlab_packed), _lib.ptr(dblab_packed),
-                                 lw, _lib.ptr(ap), _lib.ptr(nrel), _lib.stream_ptr())
-            _lib.check(rc, "wv_map_at_k")
+            rc = lib.wv_map_at_k_ld(_lib.ptr(idx), idx.stride(0), Q, k, _lib.ptr(qlab_packed), _lib.ptr(dblab_packed),
+                                    lw, _lib.ptr(ap), _lib.ptr(nrel), _lib.stream_ptr())
+            _lib.check(rc, "wv_map_at_k_ld")
     return ap, nrel
 
 

@@ -32,11 +32,15 @@ def _stacked(features_list):
 
 
 def band_attn_pool(features_list, q_eff, attn, norm1, norm2, mlp0, mlp2, out_proj, pool_mean=False,
-                   workspace=None):
-    """HIP forward of the attention-pooling core.  features_list: S x [B, E] CUDA fp32."""
+                   workspace=None, qproj_cache=None, qproj_key=None):
+    """HIP forward of the attention-pooling core.  features_list: S x [B, E] CUDA fp32.
+    qproj_cache: a dict owned by the module; holds the projected query tokens (parameters in eval mode) so that the
+    projection runs when the parameters change, not in every call; qproj_key identifies the parameters q_eff was
+    made from (storage pointers + version counters)."""
     lib = _lib.require_gpu()
     feats = _stacked(features_list)                                                   # [S, B, E]
     S, B, E = feats.shape
+    q_src = q_eff
     q_eff = q_eff.detach().float().reshape(-1, E).contiguous()
     tensors = [q_eff, attn.in_proj_weight, attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias,
                norm1.weight, norm1.bias, mlp0.weight, mlp0.bias, mlp2.weight, mlp2.bias,
@@ -51,9 +55,22 @@ def band_attn_pool(features_list, q_eff, attn, norm1, norm2, mlp0, mlp2, out_pro
     (p.q_eff, p.in_proj_w, p.in_proj_b, p.attn_out_w, p.attn_out_b, p.norm1_w, p.norm1_b, p.mlp0_w, p.mlp0_b,
      p.mlp2_w, p.mlp2_b, p.out_w, p.out_b, p.norm2_w, p.norm2_b) = [t.data_ptr() for t in keep]
     p.ln_eps = float(norm1.eps)
+    p.q_proj = None
     out = torch.empty((B, E), dtype=torch.float32, device=feats.device)
     if B == 0:
         return out
+    if qproj_cache is not None:
+        # the query tokens and the in-projection are parameters: key on their storage and version counters
+        key = (qproj_key if qproj_key is not None else (q_src.data_ptr(), q_src._version),
+               attn.in_proj_weight.data_ptr(), attn.in_proj_weight._version,
+               attn.in_proj_bias.data_ptr(), attn.in_proj_bias._version, feats.device)
+        if qproj_cache.get("key") != key:
+            qp = torch.empty_like(q_eff)
+            with torch.cuda.device(feats.device):
+                _lib.check(lib.wv_band_attn_qproj(ctypes.byref(p), _lib.ptr(qp), _lib.stream_ptr()), "wv_band_attn_qproj")
+            qproj_cache.clear()
+            qproj_cache.update(key=key, qp=qp)
+        p.q_proj = qproj_cache["qp"].data_ptr()
     ws_bytes = lib.wv_band_attn_pool_workspace_bytes(ctypes.byref(p), B)
     if workspace is None or workspace.numel() < ws_bytes or workspace.device != feats.device:
         workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=feats.device)
@@ -92,6 +109,7 @@ class CrossAttentionBottleneckHeadAdvanced(nn.Module):
         self.last_ortho_loss = 0.0
         self._ws = None
         self._zero_loss = None
+        self._qproj_cache = {}
 
     # -- pieces shared by the four variants ------------------------------------------------
     def compute_ortho_loss(self):
@@ -105,6 +123,10 @@ class CrossAttentionBottleneckHeadAdvanced(nn.Module):
 
     def effective_queries(self):
         return self.query_tokens
+
+    def _query_key(self):
+        """Identity of the parameters effective_queries() is made from (for the cached query projection)."""
+        return tuple((t.data_ptr(), t._version) for t in (self.query_tokens,))
 
     def _ortho_after_attention(self, attn_weights, mask_ll, device):
         if self.training and self.ortho_weight > 0:
@@ -137,7 +159,8 @@ class CrossAttentionBottleneckHeadAdvanced(nn.Module):
             self.last_ortho_loss = self._zero_loss
             with torch.no_grad():
                 out = band_attn_pool(kv_list, self.effective_queries(), self.attn, self.norm1, self.norm2,
-                                     self.mlp[0], self.mlp[2], self.out_proj, self._pool == "mean", self._ws)
+                                     self.mlp[0], self.mlp[2], self.out_proj, self._pool == "mean", self._ws,
+                                     self._qproj_cache, self._query_key())
             return out
 
         # training / unsupported shapes: stock PyTorch on the GPU (outside the accelerated path)
@@ -202,6 +225,9 @@ class CrossAttentionBottleneckHeadDecoupled(CrossAttentionBottleneckHeadAdvanced
         if self.normalize_queries:
             q = F.normalize(q, p=2, dim=-1)
         return q * self.query_scale
+
+    def _query_key(self):
+        return tuple((t.data_ptr(), t._version) for t in (self.query_tokens, self.query_scale)) + (self.normalize_queries,)
 
 
 _HIP_TYPES = {

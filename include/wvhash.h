@@ -226,6 +226,11 @@ int wv_rank_from_dist(const uint8_t *dist_matrix, int64_t ld_dist, int Q, int64_
 int wv_map_at_k(const int32_t *idx, int Q, int k, const uint64_t *qlab, const uint64_t *dblab,
                 int lwords, float *ap, int32_t *nrel, void *stream);
 
+/* The same over the first k entries of longer lists (row pitch ld >= k): mAP@k for several k from ONE ranking at the
+ * largest k -- evaluate_multi_k (main/engine/evaluate.py:172-245) re-ranks once per k in the reference. */
+int wv_map_at_k_ld(const int32_t *idx, int64_t ld, int Q, int k, const uint64_t *qlab, const uint64_t *dblab,
+                   int lwords, float *ap, int32_t *nrel, void *stream);
+
 /* Running hit counts along each ranked list: hits[q][p] = relevant entries among idx[q][0..p] (uint32 [Q][k]).
  * The ratios of these counts are the secondary retrieval diagnostics of accuracy_calculator.py:131-181
  * (RetrievalRPrecision, RetrievalPrecision(top_k=1), RetrievalPrecisionRecallCurve) and the full-gallery
@@ -272,9 +277,15 @@ typedef struct wv_head_params {
     const float *out_b;      /* [E] */
     const float *norm2_w, *norm2_b; /* [E] */
     float ln_eps;
+    /* optional: [Nq][E] projected queries  q_eff @ Wq^T + bq  made once by wv_band_attn_qproj (the query tokens are
+     * parameters: in eval mode their projection does not change from call to call); NULL = computed in every call */
+    const float *q_proj;
 } wv_head_params;
 
 size_t wv_band_attn_pool_workspace_bytes(const wv_head_params *p, int B);
+/* q_proj_out float32 [Nq][E] = q_eff @ in_proj_w[0:E]^T + in_proj_b[0:E] (the Q third of nn.MultiheadAttention's packed
+ * in-projection, multi_dino_attention.py:1081,1128) */
+int wv_band_attn_qproj(const wv_head_params *p, float *q_proj_out, void *stream);
 /* feats: [S][B][E] (band-major, the layout cls_tokens.chunk(4) has at :824) -> out [B][E] */
 int wv_band_attn_pool(const wv_head_params *p, const float *feats, int B, float *out,
                       void *workspace, size_t workspace_bytes, void *stream);

@@ -131,3 +131,22 @@ def test_label_modes_whole_matrix_and_pml_column_slice(setup):
     assert abs(whole - ranking.calculate_maphashing(q, ql, r, rl, 40, stable=True)) < 1e-6
     assert abs(col0 - ranking.calculate_maphashing(q, ql[:, 0], r, rl[:, 0], 40, stable=True)) < 1e-6
     assert abs(whole - col0) > 1e-3                               # the two modes are different metrics
+
+
+def test_evaluate_multi_k_ranks_once_for_all_k(setup, monkeypatch):
+    """One wv_hamming_topk launch serves every k of k_list (maphashing AND the k-NN behind map_level0): the lists are
+    ranked at the largest k, smaller k read prefixes.  Values equal per-k evaluate() runs."""
+    from wvhash.engine import hamming as Hm
+    net, dts = setup
+    calls = []
+    real = Hm.hamming_topk
+    monkeypatch.setattr(Hm, "hamming_topk", lambda *a, **kw: (calls.append(a[3]), real(*a, **kw))[1])
+    kw = dict(test_dataset=dts, epoch=3, batch_size=32, num_workers=0, distance_metric="hamming",
+              exclude=["precision_at_1", "rpr", "pr", "pr_rc", "mean_reciprocal_rank", "r_precision"])
+    res = evaluate_multi_k(net, k_list=(20, 160, 55), **kw)
+    assert calls == [160], calls                               # one ranking, at the largest k
+    monkeypatch.setattr(Hm, "hamming_topk", real)
+    for k in (20, 160, 55):
+        single = evaluate(net, k=k, **kw)["test"]
+        for key in ("maphashing_level0", "map_level0", "bit_balance_level0"):
+            assert abs(res[k]["test"][key] - single[key]) < 1e-7, (k, key)

@@ -153,3 +153,37 @@ def test_hash_tail_batched_kernel_is_bit_identical_to_per_sample_kernel(B, nbits
         del os.environ["WV_HASH_TAIL_SIMPLE"]
     for k in ("logits", "codes", "packed"):
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("ftype", ["cross_attention_advanced", "cross_attention_decoupled"])
+def test_cached_query_projection_follows_parameter_updates(ftype):
+    """The projected query tokens are kept between calls (they are parameters); an in-place update of the query
+    tokens, of the in-projection or of the query scale must invalidate them."""
+    torch.manual_seed(3)
+    head = get_fusion_head({"type": ftype, "output_dim": 384, "num_queries": 4, "sub_band_dropout_p": 0.0}, [384] * 4)
+    head = head.cuda().eval()
+    feats = [f.cuda() for f in synth.band_features(9, 384, seed=7)]
+
+    def ref():
+        sd = {k: v.detach().cpu() for k, v in head.state_dict().items()}
+        if ftype.endswith("decoupled"):
+            q = torch.nn.functional.normalize(sd["query_tokens"], p=2, dim=-1) * sd.pop("query_scale")
+            sd["query_tokens"] = q
+        return head_torch.band_attn_pool([f.cpu() for f in feats], sd, 8)
+
+    with torch.no_grad():
+        y0 = head(feats)
+        assert (y0.cpu() - ref()).abs().max() < ATOL
+        key0 = head._qproj_cache["key"]
+        head(feats)
+        assert head._qproj_cache["key"] == key0                       # second call: projection reused
+        head.query_tokens.mul_(1.5)
+        y1 = head(feats)
+        assert head._qproj_cache["key"] != key0 and (y1.cpu() - ref()).abs().max() < ATOL
+        head.attn.in_proj_weight.add_(0.01)
+        y2 = head(feats)
+        assert (y2.cpu() - ref()).abs().max() < ATOL and not torch.equal(y1, y2)
+        if ftype.endswith("decoupled"):
+            head.query_scale.mul_(0.5)
+            y3 = head(feats)
+            assert (y3.cpu() - ref()).abs().max() < ATOL and not torch.equal(y2, y3)
