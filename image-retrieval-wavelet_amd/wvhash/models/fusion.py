@@ -147,8 +147,9 @@ class CrossAttentionBottleneckHeadAdvanced(nn.Module):
     def forward(self, features_list):
         batch_size = features_list[0].shape[0]
         device = features_list[0].device
-        if not features_list[0].is_cuda:
-            raise _lib.WvhashUnavailable("fusion heads run on the GPU only (no CPU path in wvhash)")
+        if not features_list[0].is_cuda and not self.training:
+            raise _lib.WvhashUnavailable("the eval-mode fusion head runs on the GPU only (no CPU path in wvhash); the "
+                                         "training-mode forward is stock PyTorch and follows its tensors' device")
         kv_list = [proj(f) for proj, f in zip(self.projections, features_list)]
 
         if self._hip_ok(kv_list):
