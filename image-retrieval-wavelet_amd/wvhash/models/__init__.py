@@ -1,8 +1,7 @@
 from .fusion import (CrossAttentionBottleneckHead, CrossAttentionBottleneckHeadAdvanced,
                      CrossAttentionBottleneckHeadPooled, CrossAttentionBottleneckHeadDecoupled,
                      get_fusion_head, band_attn_pool)
-from .hashing import SharedDinoHashing, MultiDinoHashing, hash_tail
-from .hub_utils import load_dinov2
+from .hashing import SharedDinoHashing, MultiDinoHashing, hash_tail, load_dinov2
 
 __all__ = ["CrossAttentionBottleneckHead", "CrossAttentionBottleneckHeadAdvanced",
            "CrossAttentionBottleneckHeadPooled", "CrossAttentionBottleneckHeadDecoupled", "get_fusion_head",

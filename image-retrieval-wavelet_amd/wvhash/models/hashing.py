@@ -16,7 +16,20 @@ import torch.nn as nn
 from .. import _lib
 from ..transforms import functional as TF
 from .fusion import get_fusion_head
-from .hub_utils import load_dinov2
+
+
+def load_dinov2(name, retries=1, **kwargs):
+    """The reference's backbone loader (main/models/hub_utils.py:35-59): torch.hub, i.e. network or a populated hub
+    cache.  Offline this raises; pass ``backbone=`` / ``backbones=`` to the model classes instead (the backbone is
+    outside the accelerated path; bench and tests use wvhash.models.vit)."""
+    last = None
+    for _ in range(max(1, retries)):
+        try:
+            return torch.hub.load("facebookresearch/dinov2:main", name, skip_validation=True, **kwargs)
+        except Exception as e:  # network / cache miss
+            last = e
+    raise RuntimeError(f"load_dinov2('{name}') failed ({type(last).__name__}: {last}): construct the model with "
+                       "backbone=<nn.Module with .embed_dim> instead")
 
 
 def hash_tail(fused, hash_fc, bn, want=("codes",)):
