@@ -214,7 +214,7 @@ def kernel_table(p, reps, swt_ms_live):
         how = f"HIP events between the stages of {reps} extra full steps"
         rows.append(("wv_band_attn_pool[fp32 MFMA GEMMs + attn core + LN]", "mfma", Q * 14.2e6, st["head1"], how))
         rows.append(("wv_hash_tail", "hbm", Q * (EMBED * 4 + 8) + NBITS * EMBED * 4, st["tail1"], how))
-        rows.append(("wv_hamming_topk[k_hamming_topk 64b N=25000 k=5000]", "hbm",
+        rows.append(("wv_hamming_topk[k_rank_window 64b N=25000 k=5000]", "hbm",
                      (Q + N_DB) * NBITS // 8 + Q * TOPK * 5, st["rank1"], how))
         rows.append(("wv_map_at_k", "hbm", Q * TOPK * 4 + (Q + N_DB) * 8 + Q * 8, st["map1"], how))
         from wvhash.transforms import swt2d
@@ -266,12 +266,12 @@ def stream_ceilings(device):
 
 def load_traffic(kernel_name):
     """HBM bytes per launch from the committed rocprofv3 --pmc summary (profiles/), if present."""
-    path = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    path = os.path.join(ROOT, "profiles", "traffic_r02.json")
     try:
         with open(path) as f:
             t = json.load(f)
         for key, val in t.items():
-            if key in kernel_name:
+            if not key.startswith("_") and key in kernel_name:
                 return val["hbm_bytes_per_launch"] if isinstance(val, dict) else val
     except (OSError, ValueError):
         pass
