@@ -37,7 +37,13 @@ __device__ unsigned long long g_rank2_stamps[8];
 #define R2_STAMP_INIT do { } while (0)
 #endif
 
-constexpr int kWinBins = 32;                 // distance bins per window
+#ifndef WV_R2_WINBINS
+#define WV_R2_WINBINS 32
+#endif
+#ifndef WV_R2_W25
+#define WV_R2_W25 5
+#endif
+constexpr int kWinBins = WV_R2_WINBINS;      // distance bins per window
 constexpr int kWinRows = kWinBins + 1;       // + the dummy row
 constexpr int kMaxBins2 = 130;               // nbits <= 128
 
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(256) void k_rank2_image(const uint64_t *__restrict_
 }
 
 // minimum waves per SIMD the register allocation has to leave room for (the LDS footprint admits at least as many)
-constexpr int rank2_min_waves(int nc, int qb) { return nc * qb <= 8 ? 7 : (nc * qb <= 16 ? 6 : (nc * qb <= 25 ? 5 : (nc * qb <= 32 ? 4 : 3))); }
+constexpr int rank2_min_waves(int nc, int qb) { return nc * qb <= 8 ? 7 : (nc * qb <= 16 ? 6 : (nc * qb <= 25 ? WV_R2_W25 : (nc * qb <= 32 ? 4 : 3))); }
 
 template <int WORDS, int TPQ, int NC, int QB>
 __global__ __launch_bounds__(256, rank2_min_waves(NC, QB)) void k_rank_window(const uint64_t *__restrict__ q, const uint4 *__restrict__ img,

@@ -532,3 +532,21 @@ def test_two_step_sharded_search_on_one_gpu(Q, N, nbits, k, G, prepared):
     mi, md = H.topk_merge_cum(torch.stack(lists), cum, per, k, nbits)
     assert torch.equal(mi, full_idx) and torch.equal(md, full_d)
     assert send < min(k, per) or G == 1 or k >= N            # the trimmed prefix really is shorter than the full list
+
+
+@pytest.mark.parametrize("Q,N,k,Lc", [(64, 25000, 5000, 38), (37, 3000, 3000, 20), (9, 130, 7, 64)])
+def test_ap_of_list_prefixes_equals_ap_of_shorter_lists(Q, N, k, Lc):
+    """wv_map_at_k_ld over the first k' entries of longer lists (row pitch > k') = AP of lists ranked at k' (what lets
+    evaluate_multi_k rank once); and the oracle's within 1e-6."""
+    ql, rl = synth.multi_hot_labels(Q, Lc, 0.10, 1), synth.multi_hot_labels(N, Lc, 0.10, 2)
+    q, r = synth.structured_codes(ql, 64, 3, 4), synth.structured_codes(rl, 64, 3, 5)
+    qp, rp = H.pack_codes(q.cuda()), H.pack_codes(r.cuda())
+    idx, _ = H.hamming_topk(qp, rp, 64, k)
+    qlp, rlp = H.pack_labels(ql.cuda()), H.pack_labels(rl.cuda())
+    for kk in (k, max(1, k // 2), max(1, k // 7)):
+        short, _ = H.hamming_topk(qp, rp, 64, kk)
+        ap_prefix, n_prefix = H.map_at_k(idx, qlp, rlp, k=kk)
+        ap_short, n_short = H.map_at_k(short, qlp, rlp)
+        assert torch.equal(ap_prefix, ap_short) and torch.equal(n_prefix, n_short)
+    _, ap_ref = ranking.calculate_maphashing(q[:12], ql[:12], r, rl, k, stable=True, return_per_query=True)
+    np.testing.assert_allclose(H.map_at_k(idx, qlp, rlp)[0][:12].cpu().numpy(), ap_ref, atol=AP_TOL)
