@@ -543,6 +543,12 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
     }
 }
 
+// Decoupled roles were built and measured in round 2 (per-stage LDS ready / free counters instead of the chunk barrier:
+// 4 stages x 8 rows with producer wave pairs alternating stages, and 2 stages x 16 rows with the stage released as soon as
+// the consumers hold its rows in registers): bit-identical output, 1.22 ms and 1.16 ms against 1.08 ms for this kernel
+// (2048 images, back to back) -- polling waves and the shorter per-stage batches cost more than the barrier wait they
+// remove, which the second workgroup of the CU was already filling.  Removed; see DESIGN.md section 5.
+
 template <int L, int NLEV, int R, int TH, int NT, int MINW, typename InT, int LAYOUT, bool BF16>
 static int launch_slide(const void *in, void *out, SlideGeom g, const float *lo, const float *hi, hipStream_t st)
 {
