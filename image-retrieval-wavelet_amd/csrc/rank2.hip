@@ -98,8 +98,8 @@ template <int WORDS, int TPQ, int NC, int QB>
 __device__ __forceinline__ void rank2_distances(const uint4 *__restrict__ img, const QCode<WORDS> (&qc)[QB], int64_t N, int C,
                                                 int t, uint32_t (&dc)[QB][NC], uint32_t (&dmin)[QB])
 {
-    constexpr int UNR = 8;                                       // items per batch
-    constexpr int LPB = WORDS == 1 ? UNR / 2 : UNR;              // 16-byte loads per batch
+    constexpr int UNR = WORDS == 1 ? 16 : 8;                     // items per batch: eight 16-byte loads in flight per lane (a
+    constexpr int LPB = WORDS == 1 ? UNR / 2 : UNR;              // workgroup's time is a chain of load -> popcount rounds)
     const int first = t * C;
     const int nvalid = min(C, max(0, (int)N - first));           // N < 65536, first <= 256 * 128: plain ints
     const int rows = WORDS == 1 ? (C + 1) / 2 : C;               // image rows
@@ -251,7 +251,7 @@ __device__ __forceinline__ void rank2_one_query(const uint32_t (&dc)[NC], uint32
         }
         group_sync<TPQ>();
         // ---- count: one LDS add per item, into the row of its bin or into the dummy row.  Batches of 8 items (two
-        // cache words): one uniform branch per batch, and the scheduler may not pile up more than a batch of LDS ops
+        // cache words): one uniform branch per batch; the adds return nothing, so they simply queue up
 #pragma unroll
         for (int bw = 0; bw < NC; bw += 2) {
             if (bw * 4 < C) {                                     // uniform; items >= C of the batch hold 255 -> dummy row
@@ -264,7 +264,6 @@ __device__ __forceinline__ void rank2_one_query(const uint32_t (&dc)[NC], uint32
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
         group_sync<TPQ>();
@@ -317,13 +316,14 @@ __device__ __forceinline__ void rank2_one_query(const uint32_t (&dc)[NC], uint32
             }
             group_sync<TPQ>();
             R2_STAMP(2);
-            // ---- placement: returning LDS add = this item's rank, item number into the LDS list (or the trash slot)
+            // ---- placement: returning LDS add = this item's rank, item number into the LDS list (or the trash slot).
+            // Sixteen returning adds are in flight before the first result is used (the round trip is the cost here).
 #pragma unroll
-            for (int bw = 0; bw < NC; bw += 2) {
+            for (int bw = 0; bw < NC; bw += 4) {
                 if (bw * 4 < C) {                                 // uniform
-                    uint32_t old[8];
+                    uint32_t old[16];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
+                    for (int j = 0; j < 16; ++j) {
                         old[j] = 0;
                         if (bw + (j >> 2) < NC) {
                             const uint32_t d = (dc[bw + (j >> 2)] >> (8 * (j & 3))) & 0xffu;
@@ -333,7 +333,7 @@ __device__ __forceinline__ void rank2_one_query(const uint32_t (&dc)[NC], uint32
                         }
                     }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
+                    for (int j = 0; j < 16; ++j) {
                         if (bw + (j >> 2) < NC) {
                             const uint32_t pos = (old[j] >> cell_shift) & 0xffffu;
                             L.stage[min(pos, trash)] = (uint16_t)(first + bw * 4 + j);

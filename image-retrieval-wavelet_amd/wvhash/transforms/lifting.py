@@ -89,10 +89,11 @@ class ResizeSubBands(nn.Module):
 
     def __init__(self, size, interpolation="bilinear", max_size=None, antialias=True):
         super().__init__()
-        if not isinstance(size, (int, Sequence)):
-            raise TypeError(f"Size should be int or sequence. Got {type(size)}")
-        if isinstance(size, Sequence) and len(size) not in (1, 2):
-            raise ValueError("If size is a sequence, it should have 1 or 2 values")
+        ok = isinstance(size, int) or (isinstance(size, Sequence) and len(size) in (1, 2)
+                                       and all(isinstance(v, int) for v in size))
+        if not ok:
+            raise (TypeError if not isinstance(size, (int, Sequence)) else ValueError)(
+                f"ResizeSubBands: size must be an int or a sequence of one or two ints, got {size!r}")
         self.size, self.max_size, self.antialias = size, max_size, antialias
         self.interpolation = getattr(interpolation, "value", interpolation)
 
@@ -117,23 +118,30 @@ WAVELET_DICT = {"haar": HaarLifting, "cdf97": Cdf97Lifting}
 
 
 class CustomTransform:
+    """Tensor-side lifting DWT of the legacy CNN configs (custom_transforms.py:90-117).  Output by option pair:
+
+    ==========  ===========  ==============================================================
+    ll_only     coarse_only  result (band axis = dim -3)
+    ==========  ===========  ==============================================================
+    False       True         coarsest level: approximation stacked on its three detail bands
+    False       False        every level's bands stacked (single-level decompositions only)
+    True        True         coarsest approximation alone
+    True        False        every level's approximation stacked (single level only)
+    ==========  ===========  ==============================================================
+    """
+
     def __init__(self, decompose_levels=3, basis="haar", coarse_only=True, ll_only=False, device='cuda', dwt_mode='dwt'):
         self.dwt = WAVELET_DICT[basis](n_levels=decompose_levels)
-        self.coarse_only = coarse_only
-        self.ll_only = ll_only
         self.decompose_levels = decompose_levels
+        self.coarse_only, self.ll_only = coarse_only, ll_only
 
     def __call__(self, img):
-        l, h = self.dwt(img)
-        n = self.decompose_levels
-        if not self.ll_only:
-            if self.coarse_only:
-                return torch.cat([l[n - 1].unsqueeze(-3), h[n - 1]], dim=-3)
-            if n > 1:
-                raise NotImplementedError("Full subbands not implemented yet for decompose_levels > 1 ")
-            return torch.cat([li.unsqueeze(-3) for li in l] + [hi for hi in h], dim=-3)
+        approx, details = self.dwt(img)
         if self.coarse_only:
-            return l[n - 1]
-        if n > 1:
-            raise NotImplementedError("Full approx not implemented yet for decompose_levels > 1 ")
-        return torch.cat(l, dim=-3)
+            top = approx[-1]
+            return top if self.ll_only else torch.cat([top.unsqueeze(-3), details[-1]], dim=-3)
+        if self.decompose_levels > 1:      # levels have different sizes: nothing to stack (the reference raises as well)
+            what = "approx" if self.ll_only else "subbands"
+            raise NotImplementedError(f"Full {what} not implemented yet for decompose_levels > 1 ")
+        bands = list(approx) if self.ll_only else [a.unsqueeze(-3) for a in approx] + list(details)
+        return torch.cat(bands, dim=-3)
