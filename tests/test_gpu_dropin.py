@@ -46,9 +46,10 @@ class SynthHashing(Dataset):
         return {"image": self.transform(Image.fromarray(self.imgs[i])), "label": self.labels[i], "path": str(i)}
 
 
-def make_net(cls=SharedDinoHashing, nbits=64):
+def make_net(cls=SharedDinoHashing, nbits=64, num_queries=4):
     torch.manual_seed(0)
     kw = dict(MODEL_KWARGS, binary_config={"nbits": nbits})
+    kw["fusion_config"] = dict(kw["fusion_config"], num_queries=num_queries)
     if cls is MultiDinoHashing:
         kw["backbones_config"] = [kw.pop("backbone_config")] * 4
         net = cls(backbones=[tiny_vit() for _ in range(4)], **kw)
@@ -186,8 +187,9 @@ def test_model_path_allocates_the_sub_bands_once():
 
 
 def test_bf16_bands_under_autocast():
-    """c4 shape: bf16 autocast -> the kernel emits bf16 sub-bands directly (what autocast's first cast would make)."""
-    net = make_net(MultiDinoHashing, nbits=128).bind_transform(SWTTransform(level=1, wavelet="haar", defer=True))
+    """c4 shape (multi-DINO per sub-band, num_queries = 8, 128-bit codes, bf16 autocast): the kernel emits bf16 sub-bands
+    directly (what autocast's first cast would make), the Nq = 8 head takes the backbones' bf16 features."""
+    net = make_net(MultiDinoHashing, nbits=128, num_queries=8).bind_transform(SWTTransform(level=1, wavelet="haar", defer=True))
     x = torch.from_numpy(synth.natural_images(6, 224, 224, seed=4)).permute(0, 3, 1, 2).contiguous().cuda()
     seen = []
     hooks = [b.register_forward_pre_hook(lambda mod, args: seen.append(args[0].dtype)) for b in net.backbones]

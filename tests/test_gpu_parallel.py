@@ -1,0 +1,53 @@
+"""The sharded search with the REAL kernels on every rank: two processes share this box's one GPU, the collectives run
+over gloo (host-staged, like bench.py's rehearsal) -- RCCL needs one GPU per rank and cannot run here.  Complements
+tests/test_parallel_gloo.py, where the kernels are replaced by oracle stand-ins."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "image-retrieval-wavelet_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wvhash import parallel, synth
+    from wvhash.engine import hamming as H
+    out = {}
+    for n_db, nbits, k, ql, prepared in ((25000, 64, 5000, 96, True), (1001, 128, 600, 7, False), (40000, 64, 3000, 5, True)):
+        labels_q = synth.multi_hot_labels(world * ql, 38, 0.1, 1)
+        labels_r = synth.multi_hot_labels(n_db, 38, 0.1, 2)
+        q, r = synth.structured_codes(labels_q, nbits, 3, 4), synth.structured_codes(labels_r, nbits, 3, 5)
+        lo, hi, _ = parallel.shard_bounds(n_db, world, rank)
+        qp = H.pack_codes(q[rank * ql:(rank + 1) * ql].cuda())
+        shard = H.pack_codes(r[lo:hi].cuda())
+        shard = H.PreparedDB(shard, nbits) if prepared else shard
+        idx, d, need = parallel.sharded_hamming_topk(qp, shard, nbits, k, n_db, return_need=True)
+        hint = min(k, (int(need.item()) * 9 // 8 + 63) // 64 * 64)
+        idx_h, d_h, need_h = parallel.sharded_hamming_topk(qp, shard, nbits, k, n_db, send_hint=hint, return_need=True)
+        assert parallel.exchange_ok([need_h], hint, min(k, hi - lo + 1))
+        full_idx, full_d = H.hamming_topk(H.pack_codes(q[rank * ql:(rank + 1) * ql].cuda()), H.pack_codes(r.cuda()), nbits, k)
+        out[(n_db, nbits, k)] = (torch.equal(idx, full_idx) and torch.equal(d, full_d),
+                                 torch.equal(idx_h, full_idx) and torch.equal(d_h, full_d), int(need.item()), hint)
+    torch.save(out, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_real_kernels(tmp_path):
+    port = 29700 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        got = torch.load(os.path.join(tmp_path, f"r{rank}.pt"))
+        assert len(got) == 3
+        for key, (exact, hinted, need, hint) in got.items():
+            assert exact and hinted, (rank, key)
+            assert need <= hint
