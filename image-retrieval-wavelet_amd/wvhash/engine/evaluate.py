@@ -236,3 +236,95 @@ def evaluate_multi_k(net, train_dataset=None, val_dataset=None, test_dataset=Non
             tester.do_knn_and_accuracies(all_accuracies[query_split_name], emb, query_split_name, reference_split_names)
         results_by_k[k] = dict(all_accuracies)
     return results_by_k
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Sharded evaluation: one process per GPU (the c3 / c4 shape: COCO's 117k-image database over 8 GPUs)
+def _even_slice(n, world, rank):
+    per = (n + world - 1) // world
+    return min(n, rank * per), min(n, (rank + 1) * per), per
+
+
+@_preserve_rng
+def evaluate_sharded(net, test_dataset, k=5000, epoch=None, batch_size=64, num_workers=16, group=None, **kwargs):
+    """Hashing retrieval metrics of ``{"test": queries, "gallery": database}`` with the work split over the ranks of
+    ``group`` (torch.distributed, backend nccl = RCCL; every rank calls this with the same arguments):
+
+    * rank r embeds database rows [lo_r, hi_r) and its slice of the queries -- the codes stay on its GPU, packed;
+    * the search is wvhash.parallel.sharded_hamming_topk: all_gather of the query codes, per-shard histograms and list
+      prefixes, all_to_all, GPU merge -- the role faiss.index_cpu_to_all_gpus(shards=True) plays in the reference
+      (main/engine/get_knn.py:41-44), whose embedding sweep runs under nn.DataParallel (evaluate.py:70-71);
+    * packed database labels are all-gathered (8 bytes per row), AP is computed for the local queries, the sums and the
+      per-bit counts are all-reduced.
+    Returns ``{"test": {"epoch", "maphashing_level0", "bit_balance_level0", "worst_bit_balance_level0"}}``, the same
+    numbers as evaluate() on one GPU (lists are identical for every world size; AP sums differ by fp64 rounding only).
+    Every rank's query slice is padded to a common length by repeating its last query; the copies are not counted."""
+    import torch.distributed as dist
+    from torch.utils.data import Subset
+    from ..parallel import sharded_hamming_topk, _all_gather, _all_reduce
+    from . import hamming as H
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if not (isinstance(test_dataset, dict) and "gallery" in test_dataset and "test" in test_dataset):
+        raise ValueError("evaluate_sharded expects {'test': query dataset, 'gallery': database dataset}")
+    tester = get_tester(batch_size=batch_size, num_workers=num_workers, k=k, **kwargs)
+    net.eval()
+    n_db, n_q = len(test_dataset["gallery"]), len(test_dataset["test"])
+    lo, hi, _ = _even_slice(n_db, world, rank)
+    qlo, qhi, q_per = _even_slice(n_q, world, rank)
+
+    def embed(ds, a, b):
+        if b <= a:
+            return None, None
+        return tester.get_all_embeddings(Subset(ds, range(a, b)) if (a, b) != (0, len(ds)) else ds, net)
+
+    r_codes, r_lab = embed(test_dataset["gallery"], lo, hi)
+    q_codes, q_lab = embed(test_dataset["test"], qlo, qhi)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    nbits = (r_codes if r_codes is not None else q_codes).shape[1]
+    words = (nbits + 63) // 64
+    # ---- local queries, padded to q_per rows
+    n_local_q = max(0, qhi - qlo)
+    if n_local_q:
+        qp, qlp = H.pack_codes(q_codes), H.pack_labels(q_lab.float())
+    else:
+        qp = torch.zeros((0, words), dtype=torch.int64, device=dev)
+        qlp = torch.zeros((0, 1), dtype=torch.int64, device=dev)
+    lw = torch.tensor([qlp.shape[1] if n_local_q else 0], dtype=torch.int32, device=dev)
+    _all_reduce(lw, dist.ReduceOp.MAX, group) if world > 1 else None
+    lw = int(lw.item())
+    if not n_local_q:
+        qlp = torch.zeros((0, lw), dtype=torch.int64, device=dev)
+    pad = q_per - n_local_q
+    if pad:
+        filler_q = qp[-1:].expand(pad, -1) if n_local_q else torch.zeros((pad, words), dtype=torch.int64, device=dev)
+        filler_l = qlp[-1:].expand(pad, -1) if n_local_q else torch.zeros((pad, lw), dtype=torch.int64, device=dev)
+        qp, qlp = torch.cat([qp, filler_q]).contiguous(), torch.cat([qlp, filler_l]).contiguous()
+    # ---- database shard + labels of the whole database
+    rp = H.pack_codes(r_codes) if r_codes is not None else torch.zeros((0, words), dtype=torch.int64, device=dev)
+    per_db = _even_slice(n_db, world, 0)[2]
+    rlp_local = torch.zeros((per_db, lw), dtype=torch.int64, device=dev)
+    if r_codes is not None:
+        rlp_local[:hi - lo] = H.pack_labels(r_lab.float())
+    if world > 1:
+        rlp_all = torch.empty((world * per_db, lw), dtype=torch.int64, device=dev)
+        _all_gather(rlp_all, rlp_local, group)
+    else:
+        rlp_all = rlp_local
+    k_eff = min(int(k), n_db) if k is not None else n_db
+    idx, _ = sharded_hamming_topk(qp, rp, nbits, k_eff, n_db, group=group)
+    # global row g of shard s sits at row s * per_db + (g - lo_s) of the gathered label table = g (shards are contiguous
+    # slices of equal length per_db, the last one shorter): the gathered table is indexed by the global row directly
+    ap, _ = H.map_at_k(idx, qlp, rlp_all)
+    sums = torch.zeros(2 + nbits, dtype=torch.float64, device=dev)
+    sums[0] = ap[:n_local_q].double().sum()
+    sums[1] = float(hi - lo)
+    if hi > lo:
+        sums[2:] = H.bit_counts(rp, nbits).double()
+    if world > 1:
+        _all_reduce(sums, dist.ReduceOp.SUM, group)
+    frac = sums[2:] / sums[1]
+    balance = 1.0 - 2.0 * (frac - 0.5).abs()
+    return {"test": {"epoch": f"{epoch}", "maphashing_level0": float(sums[0].item()) / n_q,
+                     "bit_balance_level0": float(balance.mean().item()),
+                     "worst_bit_balance_level0": float(balance.min().item())}}

@@ -93,10 +93,11 @@ class BaseWaveletTransform(object):
 
 def find_wavelet_transform(obj):
     """The wavelet plugin inside a transform pipeline (a plugin itself, a Compose-like object with a
-    ``transforms`` list, or a dataset with a ``transform`` attribute); None when there is none."""
+    ``transforms`` list, a dataset with a ``transform`` attribute, or a wrapper such as torch.utils.data.Subset holding
+    one in ``dataset``); None when there is none."""
     if isinstance(obj, BaseWaveletTransform):
         return obj
-    for attr in ("transform", "transforms"):
+    for attr in ("transform", "transforms", "dataset"):
         inner = getattr(obj, attr, None)
         if inner is None:
             continue

@@ -51,3 +51,42 @@ def test_two_ranks_on_one_gpu_real_kernels(tmp_path):
         for key, (exact, hinted, need, hint) in got.items():
             assert exact and hinted, (rank, key)
             assert need <= hint
+
+
+def _eval_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "image-retrieval-wavelet_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from test_gpu_dropin import NODES, SynthHashing, make_net
+    from wvhash.engine import evaluate, evaluate_sharded
+    from wvhash.transforms import build_transform
+    out = {}
+    for defer in (True, False):
+        tf = build_transform(NODES[0], defer=defer)
+        dts = {"test": SynthHashing(11, 1, tf), "gallery": SynthHashing(45, 2, tf)}      # ragged: 11 queries, 45 rows / 2 ranks
+        net = make_net()
+        m = evaluate_sharded(net, dts, k=20, epoch=2, batch_size=8, num_workers=2 if not defer else 0,
+                             distance_metric="hamming")
+        single = evaluate(net, test_dataset=dts, k=20, epoch=2, batch_size=8, num_workers=0, distance_metric="hamming",
+                          exclude=["map", "precision_at_1", "rpr", "pr", "pr_rc", "mean_reciprocal_rank", "r_precision"])
+        out[defer] = (m["test"], {k_: v for k_, v in single["test"].items() if k_ in m["test"]})
+    torch.save(out, os.path.join(out_dir, f"e{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_evaluate_sharded_equals_single_gpu_evaluate(tmp_path):
+    """evaluate_sharded on two ranks (each embeds its slice of the database and of the queries, sharded search, gathered
+    labels, all-reduced sums) reports the numbers of evaluate() -- with deferred raw batches and with the unedited
+    transform node running in DataLoader workers."""
+    port = 29800 + os.getpid() % 2000
+    mp.spawn(_eval_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        got = torch.load(os.path.join(tmp_path, f"e{rank}.pt"))
+        for defer, (sharded, single) in got.items():
+            assert sharded["epoch"] == single["epoch"] == "2"
+            for key in ("maphashing_level0", "bit_balance_level0", "worst_bit_balance_level0"):
+                assert abs(sharded[key] - single[key]) < 1e-6, (rank, defer, key, sharded[key], single[key])
