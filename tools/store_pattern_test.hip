@@ -154,6 +154,26 @@ __global__ __launch_bounds__(256) void kN(float *out, float v, int planes)
     }
 }
 
+// Q: what torch's fill does: short-lived workgroups, one float4 per thread, consecutive workgroups = consecutive 4 KB
+__global__ __launch_bounds__(256) void kQ(float4 *out, float v)
+{
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = make_float4(v, v, v, v);
+}
+// R: the same with 4 float4 per thread (16 KB per workgroup), still short-lived
+__global__ __launch_bounds__(256) void kR(float4 *out, float v)
+{
+    float4 *o = out + (size_t)blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i * 256] = make_float4(v, v, v, v + i);
+}
+// T: persistent (2048 workgroups), but every workgroup writes long contiguous runs: 64 KB per iteration
+__global__ __launch_bounds__(256) void kT(float4 *out, size_t n4, float v)
+{
+    for (size_t base = (size_t)blockIdx.x * 4096; base < n4; base += (size_t)gridDim.x * 4096)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) out[base + i * 256 + threadIdx.x] = make_float4(v, v, v, v + i);
+}
+
 int main()
 {
     const int B = 2048;
@@ -162,7 +182,7 @@ int main()
     CK(hipMalloc(&out, n * 4));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int which = 0; which < 16; ++which) {
+    for (int which = 0; which < 19; ++which) {
         float best = 1e9f;
         for (int rep = 0; rep < 5; ++rep) {
             CK(hipEventRecord(e0));
@@ -178,6 +198,9 @@ int main()
             if (which == 9) hipLaunchKernelGGL((kF<0, 256>), dim3(1024), dim3(256), 0, 0, out, 1.0f, 3 * B);
             if (which == 10) hipLaunchKernelGGL(kG, dim3(1024), dim3(256), 0, 0, out, 1.0f, 3 * B);
             if (which == 11) hipLaunchKernelGGL(kH, dim3(1024), dim3(256), 0, 0, out, 1.0f, 3 * B);
+            if (which == 16) hipLaunchKernelGGL(kQ, dim3((unsigned)(n / 4 / 256)), dim3(256), 0, 0, (float4 *)out, 1.0f);
+            if (which == 17) hipLaunchKernelGGL(kR, dim3((unsigned)(n / 4 / 1024)), dim3(256), 0, 0, (float4 *)out, 1.0f);
+            if (which == 18) hipLaunchKernelGGL(kT, dim3(2048), dim3(256), 0, 0, (float4 *)out, n / 4, 1.0f);
             if (which == 12) hipLaunchKernelGGL((kM<256>), dim3(512), dim3(256), 0, 0, out, 1.0f, 3 * B);
             if (which == 13) hipLaunchKernelGGL((kM<256>), dim3(1024), dim3(256), 0, 0, out, 1.0f, 3 * B);
             if (which == 14) hipLaunchKernelGGL(kN, dim3(512), dim3(256), 0, 0, out, 1.0f, 3 * B);
