@@ -90,3 +90,22 @@ def test_evaluate_sharded_equals_single_gpu_evaluate(tmp_path):
             assert sharded["epoch"] == single["epoch"] == "2"
             for key in ("maphashing_level0", "bit_balance_level0", "worst_bit_balance_level0"):
                 assert abs(sharded[key] - single[key]) < 1e-6, (rank, defer, key, sharded[key], single[key])
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how the driver calls it) starts two ranks itself and
+    prints ONE JSON line; on this 1-GPU box the ranks share the GPU and the collectives are staged over gloo, which the
+    line says."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "WV_DIST_BACKEND")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--queries", "256"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["config"]["exchange"]["verified_exact"] is True
+    if torch.cuda.device_count() < 2:
+        assert "REHEARSAL" in rec["config"]["backend"]
