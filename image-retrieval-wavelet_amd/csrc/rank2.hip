@@ -14,12 +14,15 @@
 //     (global index = item + idx_offset), the distance row is regenerated from the bin boundaries, 16 bytes per store;
 //   * TPQ = 64 runs one query per WAVE (no workgroup barrier at all, 4 queries per workgroup): the shape of a
 //     row-sharded search, many queries against few rows each.
-//   * the database image is the traffic that matters (phase stamps: 70 % of the first windowed version went into loading
-//     it -- every query's workgroup streams the whole image from L2, 410 MB per launch at c1): a group now computes the
-//     distances of QB queries from ONE pass over the image (the queries are then ranked one after the other through the
-//     same LDS), and a lane loads 16 bytes (two 64-bit codes) per instruction;
-// Covers N < 65536 (16-bit item numbers / counters), C <= 128 items per thread (distances cached in registers as
-// bytes), k small enough for the LDS list; everything else stays on topk.hip's kernel.
+//   * a workgroup's time is a chain of latencies (phase stamps), so loads and returning LDS adds are kept
+//     deep in flight: a lane loads 16 bytes of the database image (two 64-bit codes) per instruction, eight loads per
+//     batch, sixteen returning adds before the first rank is used.  The kernel can compute the distances of QB queries
+//     from one pass over the image (template parameter; the queries are then ranked one after the other through the same
+//     LDS) -- measured slower than QB = 1 at every shape, so only QB = 1 is instantiated;
+//   * k = 0 is a histogram-only mode (one count pass over all bins), rows16 output writes 16-bit local row numbers:
+//     the two steps of the sharded search (wv_hamming_hist, wv_hamming_topk_rows16).
+// Covers databases (shards) of at most 32,768 rows -- C <= 128 items per thread, their distances cached in registers as
+// bytes; 16-bit item numbers and counters -- and k small enough for the LDS list; everything else stays on topk.hip's kernel.
 #include "common.hpp"
 
 namespace wv {
