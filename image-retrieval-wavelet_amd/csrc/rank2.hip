@@ -504,8 +504,8 @@ int rank2_tpq(int Q, int64_t N, int k)
     if (N >= 65536 || k + 128 >= 65536) return 0;
     const bool fits256 = N <= 256 * 128 && rank2_lds_bytes_per_query<256>(k) <= 100 * 1024;
     const bool fits64 = ceil_div(N, 64) <= 64 && 4 * rank2_lds_bytes_per_query<64>(k) <= 100 * 1024;
-    if (force && atoi(force) == 64) return fits64 ? 64 : 0;
-    if (force && atoi(force) == 256) return fits256 ? 256 : 0;
+    if (force && atoi(force) == 64 && fits64) return 64;        // a pinned variant that does not fit the shape is ignored
+    if (force && atoi(force) == 256 && fits256) return 256;
     // one wave per query pays when each query has little work and there are enough queries to fill the chip
     if (fits64 && N <= 4096 && Q >= 4096) return 64;
     return fits256 ? 256 : (fits64 ? 64 : 0);
