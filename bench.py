@@ -212,7 +212,13 @@ def kernel_table(p, reps, swt_ms_live):
         rows.append(("wv_swt2d_forward[k_swt_slide db2 L3 u8->f32]", "hbm", swt_bytes, swt_ms_live,
                      "HIP events around the launch in every timed step"))
         how = f"HIP events between the stages of {reps} extra full steps"
-        rows.append(("wv_band_attn_pool[fp32 MFMA GEMMs + attn core + LN]", "mfma", Q * 14.2e6, st["head1"], how))
+        # executed flops per sample: V 4x384x384, scores 4x384x32 (K projection folded into the query tokens), attention
+        # out-projection 4x384x384, mlp 2 x 4x384x1536, read-out 1536x384 -- 13.07 MFLOP (the separate-launch path,
+        # which projects K as well, executes 14.2)
+        head_flops = 2 * (4 * EMBED * EMBED + 4 * EMBED * NQ * HEADS + NQ * EMBED * EMBED + 2 * NQ * EMBED * 4 * EMBED
+                          + NQ * EMBED * EMBED)
+        rows.append(("wv_band_attn_pool[3 launches: fused front k_head_front (V, scores, softmax, out-proj, LN, MLP; fp32 "
+                     "MFMA) + read-out GEMM + LN]", "mfma", Q * head_flops, st["head1"], how))
         rows.append(("wv_hash_tail", "hbm", Q * (EMBED * 4 + 8) + NBITS * EMBED * 4, st["tail1"], how))
         rows.append(("wv_hamming_topk[k_rank_window 64b N=25000 k=5000]", "hbm",
                      (Q + N_DB) * NBITS // 8 + Q * TOPK * 5, st["rank1"], how))

@@ -752,6 +752,11 @@ static HeadWs carve(const wv_head_params *p, int B, void *base)
     return w;
 }
 
+// head_front.hip: the fused front (band features -> x2 in one launch) and its prepared weight stream
+size_t head_front_prepared_bytes(const wv_head_params *p);
+int head_front_prepare(const wv_head_params *p, void *prepared, hipStream_t st);
+int head_front_launch(const wv_head_params *p, const float *feats, int B, float *x2, int mode, hipStream_t st);
+
 }  // namespace wv
 
 using namespace wv;
@@ -790,6 +795,20 @@ extern "C" int wv_band_attn_qproj(const wv_head_params *p, float *q_proj_out, vo
     return WV_OK;
 }
 
+extern "C" size_t wv_band_attn_prepared_bytes(const wv_head_params *p)
+{
+    if (!p || check_head(p, 1)) return 0;
+    return head_front_prepared_bytes(p);
+}
+
+extern "C" int wv_band_attn_prepare(const wv_head_params *p, void *prepared_out, void *stream)
+{
+    int rc = check_head(p, 1);
+    if (rc) return rc;
+    WV_REQUIRE(prepared_out, "band_attn_prepare: null buffer");
+    return head_front_prepare(p, prepared_out, (hipStream_t)stream);
+}
+
 extern "C" int wv_band_attn_pool(const wv_head_params *p, const float *feats, int B, float *out,
                                  void *workspace, size_t workspace_bytes, void *stream)
 {
@@ -805,25 +824,32 @@ extern "C" int wv_band_attn_pool(const wv_head_params *p, const float *feats, in
     const int E = p->embed_dim, Nq = p->num_queries, S = p->num_tokens, rows = B * Nq;
     HeadWs w = carve(p, B, workspace);
 
-    // Q projection (batch-invariant): Qp = q_eff @ Wq^T + bq -- taken from the caller when it was made ahead of time
-    const float *Qp = p->q_proj;
-    if (!Qp) {
-        hipLaunchKernelGGL(k_qproj, dim3((unsigned)ceil_div(Nq * E, 4)), dim3(256), 0, st, p->q_eff, p->in_proj_w,
-                           p->in_proj_b, w.Qp, Nq, E);
-        Qp = w.Qp;
+    // prepared weights: everything up to x2 in one launch when the batch fills the chip (WV_HEAD_FRONT=0 / 1 pins
+    // the separate launches / the one-launch front for tests and A/B runs)
+    const char *pin = getenv("WV_HEAD_FRONT");
+    const int mode = pin && !strcmp(pin, "0") ? 0 : pin && !strcmp(pin, "1") ? 1 : -1;
+    const bool fused = p->prepared && head_front_launch(p, feats, B, w.x2, mode, st);
+    if (!fused) {
+        // Q projection (batch-invariant): Qp = q_eff @ Wq^T + bq -- taken from the caller when it was made ahead of time
+        const float *Qp = p->q_proj ? p->q_proj : reinterpret_cast<const float *>(p->prepared);   // the blob starts with it
+        if (!Qp) {
+            hipLaunchKernelGGL(k_qproj, dim3((unsigned)ceil_div(Nq * E, 4)), dim3(256), 0, st, p->q_eff, p->in_proj_w,
+                               p->in_proj_b, w.Qp, Nq, E);
+            Qp = w.Qp;
+        }
+        // K | V projection of all S*B tokens: rows E..3E of in_proj_weight
+        launch_gemm<EPI_NONE>(feats, p->in_proj_w + (size_t)E * E, p->in_proj_b + E, nullptr, 1, w.KV, S * B, 2 * E, E, st);
+        const size_t sm = ((size_t)S * (2 * E + 4) + (size_t)Nq * E + (size_t)Nq * p->num_heads * S) * sizeof(float);
+        if (sm > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn_core), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        hipLaunchKernelGGL(k_attn_core, dim3(B), dim3(256), sm, st, Qp, w.KV, w.ctx, B, E, p->num_heads, Nq, S);
+        // x1 = q_eff + ctx @ Wo^T + bo ; x1n = LN1(x1)
+        launch_gemm<EPI_ADD_BCAST>(w.ctx, p->attn_out_w, p->attn_out_b, p->q_eff, Nq, w.x1, rows, E, E, st);
+        launch_layernorm(w.x1, p->norm1_w, p->norm1_b, w.x1n, (int64_t)rows, E, p->ln_eps, 1, st);
+        // x2 = x1n + GELU(x1n @ W0^T + b0) @ W2^T + b2
+        launch_gemm<EPI_GELU>(w.x1n, p->mlp0_w, p->mlp0_b, nullptr, 1, w.hid, rows, 4 * E, E, st);
+        launch_gemm<EPI_ADD_ROW>(w.hid, p->mlp2_w, p->mlp2_b, w.x1n, 1, w.x2, rows, E, 4 * E, st);
     }
-    // K | V projection of all S*B tokens: rows E..3E of in_proj_weight
-    launch_gemm<EPI_NONE>(feats, p->in_proj_w + (size_t)E * E, p->in_proj_b + E, nullptr, 1, w.KV, S * B, 2 * E, E, st);
-    const size_t sm = ((size_t)S * (2 * E + 4) + (size_t)Nq * E + (size_t)Nq * p->num_heads * S) * sizeof(float);
-    if (sm > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn_core), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    hipLaunchKernelGGL(k_attn_core, dim3(B), dim3(256), sm, st, Qp, w.KV, w.ctx, B, E, p->num_heads, Nq, S);
-    // x1 = q_eff + ctx @ Wo^T + bo ; x1n = LN1(x1)
-    launch_gemm<EPI_ADD_BCAST>(w.ctx, p->attn_out_w, p->attn_out_b, p->q_eff, Nq, w.x1, rows, E, E, st);
-    launch_layernorm(w.x1, p->norm1_w, p->norm1_b, w.x1n, (int64_t)rows, E, p->ln_eps, 1, st);
-    // x2 = x1n + GELU(x1n @ W0^T + b0) @ W2^T + b2
-    launch_gemm<EPI_GELU>(w.x1n, p->mlp0_w, p->mlp0_b, nullptr, 1, w.hid, rows, 4 * E, E, st);
-    launch_gemm<EPI_ADD_ROW>(w.hid, p->mlp2_w, p->mlp2_b, w.x1n, 1, w.x2, rows, E, 4 * E, st);
     // read-out: concat (a [B][Nq*E] view of x2) or mean over the queries, then Linear + LN2
     const float *ro_in = w.x2;
     int ro_k = Nq * E;

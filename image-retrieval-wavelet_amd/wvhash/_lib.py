@@ -39,6 +39,7 @@ class HeadParams(ctypes.Structure):
         ("norm2_w", ctypes.c_void_p), ("norm2_b", ctypes.c_void_p),
         ("ln_eps", ctypes.c_float),
         ("q_proj", ctypes.c_void_p),
+        ("prepared", ctypes.c_void_p),
     ]
 
 
@@ -83,6 +84,8 @@ SIGNATURES = {
     "wv_knn_float": (_i, [_vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "wv_band_attn_pool_workspace_bytes": (_sz, [ctypes.POINTER(HeadParams), _i]),
     "wv_band_attn_qproj": (_i, [ctypes.POINTER(HeadParams), _vp, _vp]),
+    "wv_band_attn_prepared_bytes": (_sz, [ctypes.POINTER(HeadParams)]),
+    "wv_band_attn_prepare": (_i, [ctypes.POINTER(HeadParams), _vp, _vp]),
     "wv_band_attn_pool": (_i, [ctypes.POINTER(HeadParams), _vp, _i, _vp, _vp, _sz, _vp]),
     "wv_hash_tail": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),
 }

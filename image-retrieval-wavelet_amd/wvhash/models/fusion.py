@@ -34,9 +34,10 @@ def _stacked(features_list):
 def band_attn_pool(features_list, q_eff, attn, norm1, norm2, mlp0, mlp2, out_proj, pool_mean=False,
                    workspace=None, qproj_cache=None, qproj_key=None):
     """HIP forward of the attention-pooling core.  features_list: S x [B, E] CUDA fp32.
-    qproj_cache: a dict owned by the module; holds the projected query tokens (parameters in eval mode) so that the
-    projection runs when the parameters change, not in every call; qproj_key identifies the parameters q_eff was
-    made from (storage pointers + version counters)."""
+    qproj_cache: a dict owned by the module; holds what is made from parameters alone -- the projected query tokens and,
+    for the configurations with a one-launch front (wv_band_attn_prepared_bytes), the fragment-ordered copy of the
+    weights -- so that it is rebuilt when a parameter changes, not in every call; qproj_key identifies the parameters
+    q_eff was made from (storage pointers + version counters)."""
     lib = _lib.require_gpu()
     feats = _stacked(features_list)                                                   # [S, B, E]
     S, B, E = feats.shape
@@ -59,18 +60,29 @@ def band_attn_pool(features_list, q_eff, attn, norm1, norm2, mlp0, mlp2, out_pro
     out = torch.empty((B, E), dtype=torch.float32, device=feats.device)
     if B == 0:
         return out
+    p.prepared = None
     if qproj_cache is not None:
-        # the query tokens and the in-projection are parameters: key on their storage and version counters
+        # the query tokens and the weights are parameters: key on their storage and version counters
+        watched = (attn.in_proj_weight, attn.in_proj_bias, attn.out_proj.weight, mlp0.weight, mlp2.weight)
         key = (qproj_key if qproj_key is not None else (q_src.data_ptr(), q_src._version),
-               attn.in_proj_weight.data_ptr(), attn.in_proj_weight._version,
-               attn.in_proj_bias.data_ptr(), attn.in_proj_bias._version, feats.device)
+               tuple((t.data_ptr(), t._version) for t in watched), attn.num_heads, S, feats.device)
         if qproj_cache.get("key") != key:
-            qp = torch.empty_like(q_eff)
             with torch.cuda.device(feats.device):
-                _lib.check(lib.wv_band_attn_qproj(ctypes.byref(p), _lib.ptr(qp), _lib.stream_ptr()), "wv_band_attn_qproj")
+                nbytes = lib.wv_band_attn_prepared_bytes(ctypes.byref(p))
+                if nbytes:      # this configuration has the one-launch front: projected queries + fragment-ordered weights
+                    blob = torch.empty(nbytes, dtype=torch.uint8, device=feats.device)
+                    _lib.check(lib.wv_band_attn_prepare(ctypes.byref(p), _lib.ptr(blob), _lib.stream_ptr()), "wv_band_attn_prepare")
+                    entry = dict(key=key, blob=blob, qp=None)
+                else:
+                    qp = torch.empty_like(q_eff)
+                    _lib.check(lib.wv_band_attn_qproj(ctypes.byref(p), _lib.ptr(qp), _lib.stream_ptr()), "wv_band_attn_qproj")
+                    entry = dict(key=key, blob=None, qp=qp)
             qproj_cache.clear()
-            qproj_cache.update(key=key, qp=qp)
-        p.q_proj = qproj_cache["qp"].data_ptr()
+            qproj_cache.update(entry)
+        if qproj_cache["blob"] is not None:
+            p.prepared = qproj_cache["blob"].data_ptr()
+        else:
+            p.q_proj = qproj_cache["qp"].data_ptr()
     ws_bytes = lib.wv_band_attn_pool_workspace_bytes(ctypes.byref(p), B)
     if workspace is None or workspace.numel() < ws_bytes or workspace.device != feats.device:
         workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=feats.device)

@@ -280,12 +280,24 @@ typedef struct wv_head_params {
     /* optional: [Nq][E] projected queries  q_eff @ Wq^T + bq  made once by wv_band_attn_qproj (the query tokens are
      * parameters: in eval mode their projection does not change from call to call); NULL = computed in every call */
     const float *q_proj;
+    /* optional: the blob wv_band_attn_prepare wrote (projected queries + the weights of every product up to the MLP
+     * output in MFMA-fragment order, with the K projection folded into the queries).  When set, and the configuration
+     * has a fused kernel (wv_band_attn_prepared_bytes != 0), everything before the read-out product runs as ONE
+     * launch (csrc/head_front.hip) and q_proj is not needed.  It is a snapshot of in_proj_w, q_eff, attn_out_w, mlp0_w,
+     * mlp2_w: make it again whenever one of them changes.  NULL = separate launches (any configuration). */
+    const void *prepared;
 } wv_head_params;
 
 size_t wv_band_attn_pool_workspace_bytes(const wv_head_params *p, int B);
 /* q_proj_out float32 [Nq][E] = q_eff @ in_proj_w[0:E]^T + in_proj_b[0:E] (the Q third of nn.MultiheadAttention's packed
  * in-projection, multi_dino_attention.py:1081,1128) */
 int wv_band_attn_qproj(const wv_head_params *p, float *q_proj_out, void *stream);
+/* Size of the prepared blob for this configuration; 0 = no fused kernel (E = 384, 4 band tokens and 4 or 8 queries
+ * have one), use the separate-launch path.  wv_band_attn_prepare fills `prepared_out` (device memory of that size) on
+ * `stream`; p->q_proj and p->prepared are ignored by it.  The weights are parameters (multi_dino_attention.py:1064-1109):
+ * in eval mode the blob is made once per parameter update, like q_proj. */
+size_t wv_band_attn_prepared_bytes(const wv_head_params *p);
+int wv_band_attn_prepare(const wv_head_params *p, void *prepared_out, void *stream);
 /* feats: [S][B][E] (band-major, the layout cls_tokens.chunk(4) has at :824) -> out [B][E] */
 int wv_band_attn_pool(const wv_head_params *p, const float *feats, int B, float *out,
                       void *workspace, size_t workspace_bytes, void *stream);

@@ -40,7 +40,11 @@ def build(n, gold):
     return head.cuda().eval(), synth.band_features(B, E, seed + 1000), sd
 
 
-def test_heads_match_reference_module_outputs(gold):
+@pytest.mark.parametrize("front", ["0", "1"])
+def test_heads_match_reference_module_outputs(gold, front, monkeypatch):
+    """front = "1": the one-launch front (csrc/head_front.hip) wherever the configuration has one (E = 384 with 4 or 8
+    queries: five of the seven cases); "0": the separate launches for all of them."""
+    monkeypatch.setenv("WV_HEAD_FRONT", front)
     names = sorted({k.split("/")[0] for k in gold.files if k.endswith("/meta")})
     assert len(names) == 7
     for n in names:
@@ -52,8 +56,10 @@ def test_heads_match_reference_module_outputs(gold):
         assert float(head.last_ortho_loss) == 0.0
 
 
+@pytest.mark.parametrize("front", ["0", "1"])
 @pytest.mark.parametrize("B", [1, 63, 256, 2048])
-def test_batch_sizes_against_oracle(B):
+def test_batch_sizes_against_oracle(B, front, monkeypatch):
+    monkeypatch.setenv("WV_HEAD_FRONT", front)
     sd = synth.head_state(384, 4, "concat", seed=5)
     head = get_fusion_head({"type": "cross_attention_advanced", "output_dim": 384, "num_queries": 4}, [384] * 4)
     head.load_state_dict(sd)
@@ -67,6 +73,53 @@ def test_batch_sizes_against_oracle(B):
     assert (y.cpu() - ref).abs().max().item() < ATOL
     ref64 = head_torch.band_attn_pool(feats[:1] if False else feats, sd, 8, dtype=torch.float64)
     assert (y.cpu().double() - ref64).abs().max().item() < ATOL
+
+
+@pytest.mark.parametrize("nq,heads,B", [(4, 8, 2048), (4, 8, 1155), (8, 8, 600), (4, 12, 100), (8, 6, 37), (4, 16, 9),
+                                        (8, 16, 70), (4, 2, 17)])
+def test_one_launch_front_against_separate_launches_and_oracle(nq, heads, B, monkeypatch):
+    """The fused front folds the K projection into the query tokens and mixes V in registers: same function, other
+    summation order.  Both paths must sit within the golden tolerance of the fp64 oracle and within 2e-5 of each other;
+    the prepared weight stream covers 1, 2 and 4 score blocks (Nq * heads = 32 ... 128) and partial last workgroups."""
+    sd = synth.head_state(384, nq, "concat", seed=nq * 31 + heads)
+    head = get_fusion_head({"type": "cross_attention_advanced", "output_dim": 384, "num_queries": nq, "num_heads": heads},
+                           [384] * 4)
+    head.load_state_dict(sd)
+    head = head.cuda().eval()
+    feats = synth.band_features(B, 384, seed=B + heads)
+    dev = [f.cuda() for f in feats]
+    out = {}
+    with torch.no_grad():
+        for front in ("1", "0"):
+            monkeypatch.setenv("WV_HEAD_FRONT", front)
+            out[front] = head(dev).cpu()
+    assert head._qproj_cache["blob"] is not None                 # this configuration has a prepared stream
+    assert not torch.equal(out["0"], out["1"])                   # two different kernels did run
+    assert (out["0"] - out["1"]).abs().max().item() < 2e-5
+    ref = head_torch.band_attn_pool(feats, sd, heads, dtype=torch.float64)
+    for front in ("0", "1"):
+        assert (out[front].double() - ref).abs().max().item() < ATOL, front
+
+
+def test_front_is_chosen_by_batch_size_and_unsupported_shapes_fall_back(monkeypatch):
+    monkeypatch.delenv("WV_HEAD_FRONT", raising=False)
+    head = get_fusion_head({"type": "cross_attention_advanced", "output_dim": 384, "num_queries": 4}, [384] * 4)
+    head.load_state_dict(synth.head_state(384, 4, "concat", seed=2))
+    head = head.cuda().eval()
+    small = [f.cuda() for f in synth.band_features(64, 384, seed=1)]
+    big = [f.cuda() for f in synth.band_features(1536, 384, seed=1)]
+    with torch.no_grad():
+        auto_small, auto_big = head(small), head(big)
+        monkeypatch.setenv("WV_HEAD_FRONT", "0")
+        sep_small, sep_big = head(small), head(big)
+    assert torch.equal(auto_small, sep_small)                    # 8 workgroups: the separate launches
+    assert not torch.equal(auto_big, sep_big) and (auto_big - sep_big).abs().max().item() < 2e-5   # 192 workgroups: one launch
+    monkeypatch.setenv("WV_HEAD_FRONT", "1")
+    other = get_fusion_head({"type": "cross_attention_advanced", "output_dim": 64, "num_queries": 4, "num_heads": 4}, [64] * 4)
+    other = other.cuda().eval()                                   # E = 64 has no fused kernel: no blob, separate launches
+    with torch.no_grad():
+        y = other([f.cuda() for f in synth.band_features(5, 64, seed=3)])
+    assert other._qproj_cache["blob"] is None and other._qproj_cache["qp"] is not None and torch.isfinite(y).all()
 
 
 def test_hip_path_equals_stock_torch_forward_of_same_module():
@@ -156,9 +209,11 @@ def test_hash_tail_batched_kernel_is_bit_identical_to_per_sample_kernel(B, nbits
 
 
 @pytest.mark.parametrize("ftype", ["cross_attention_advanced", "cross_attention_decoupled"])
-def test_cached_query_projection_follows_parameter_updates(ftype):
+@pytest.mark.parametrize("front", ["0", "1"])
+def test_cached_query_projection_follows_parameter_updates(ftype, front, monkeypatch):
     """The projected query tokens are kept between calls (they are parameters); an in-place update of the query
     tokens, of the in-projection or of the query scale must invalidate them."""
+    monkeypatch.setenv("WV_HEAD_FRONT", front)
     torch.manual_seed(3)
     head = get_fusion_head({"type": ftype, "output_dim": 384, "num_queries": 4, "sub_band_dropout_p": 0.0}, [384] * 4)
     head = head.cuda().eval()
@@ -183,6 +238,11 @@ def test_cached_query_projection_follows_parameter_updates(ftype):
         head.attn.in_proj_weight.add_(0.01)
         y2 = head(feats)
         assert (y2.cpu() - ref()).abs().max() < ATOL and not torch.equal(y1, y2)
+        for w in (head.attn.out_proj.weight, head.mlp[0].weight, head.mlp[2].weight):   # copied into the prepared stream
+            w.add_(0.01)
+            y2b = head(feats)
+            assert (y2b.cpu() - ref()).abs().max() < ATOL and not torch.equal(y2, y2b)
+            y2 = y2b
         if ftype.endswith("decoupled"):
             head.query_scale.mul_(0.5)
             y3 = head(feats)
