@@ -49,7 +49,11 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--clock-steps", type=int, default=40,
+                    help="untimed steps run BEFORE the --warmup steps: after an idle period the compute-bound kernels keep "
+                         "speeding up for ~25 steps (~35 ms) while the GPU's clocks ramp (kernel trace: head front 265 -> 212 us, "
+                         "ranking 63 -> 49 us, the HBM-bound SWT unchanged); 0 = measure the ramp")
     ap.add_argument("--queries", type=int, default=Q_PER_GPU, help="query images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("WV_BENCH_STREAMS", "1")), choices=(1, 2),
@@ -184,8 +188,8 @@ def stage_times_in_pipeline(p, reps):
     """Average device time of every stage inside full steps (HIP events between the stages, on the launch stream).
     A stage timed alone, back to back, can read differently: the SWT kernel run 10x in a row averages ~8 % slower
     than inside the step, where the head's compute-bound kernels give the write stream time to drain."""
-    p.step()
-    torch.cuda.synchronize()
+    for _ in range(30):     # back to steady clocks first (the timed loop may lie an idle period behind us)
+        p.step()
     p.marks, p.marks_all = [], True
     for _ in range(reps):
         p.step()
@@ -428,6 +432,8 @@ def main():
 
     out = p.step()                     # untimed: sizes the list exchange exactly (one host read), compiles nothing
     p.learn_send_hint()
+    for _ in range(args.clock_steps):  # bring the clocks up (reported in config.clock_steps)
+        p.step()
     for _ in range(args.warmup):
         out = p.step()
     barrier()
@@ -481,6 +487,7 @@ def main():
             "wavelet": WAVELET, "level": LEVEL,
             "arithmetic": "fp32 SWT and head (fp32 MFMA), 64-bit popcount ranking, AP in fp32/fp64",
             "streams": args.streams,
+            "clock_steps": args.clock_steps,   # untimed steps before the warm-up steps (GPU clock ramp after idle)
             "backend": (("rccl" if dist.get_backend() == "nccl" else
                          f"{dist.get_backend()} (REHEARSAL: {world} ranks share {torch.cuda.device_count()} GPU(s), "
                          "collectives staged through host memory)") if world > 1 else "none"),

@@ -143,6 +143,28 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 #define HF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// GELU(v) = 0.5 v (1 + erf(v / sqrt 2)) (nn.GELU() default, multi_dino_attention.py:1098).  erfc(|x|) by Abramowitz &
+// Stegun 7.1.26 (absolute error <= 1.5e-7, i.e. fp32 rounding of an O(1) value), 1 + erf taken as erfc(|x|) on the
+// negative side so that nothing cancels: 14 instructions against ~40 of the library erff.  The activation runs with
+// the matrix pipe idle: VALU work of the SAME wave does not overlap its MFMAs here (activating the A fragments inside
+// the mlp.2 product instead, ~66 VALU instructions spread between the 12 MFMAs of each step, took the exposed 6 %
+// away and added 17 % to the product: measured, dropped).  -DWV_HF_EXACT_ERF restores erff.
+__device__ __forceinline__ float gelu_erf(float v)
+{
+#ifdef WV_HF_EXACT_ERF
+    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+#else
+    const float x = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));   // v_rcp_f32 (1 ulp); the IEEE division is 11 instructions
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float erfc_abs = p * t * __expf(-x * x);
+    return 0.5f * v * (v >= 0.f ? 2.0f - erfc_abs : erfc_abs);
+#endif
+}
+
 // acc[b] += A[32 x 8*NE] . B_b over NE stream entries (entry c = k-chunk c of the wave's three 32-column blocks).
 // Ring invariant on entry and exit: slots 0..D-2 hold (or have in flight) the next D-1 entries, wq is the address of
 // the entry after them.  Each step first refills the slot the previous step consumed, then reads the next A fragment,
@@ -245,26 +267,6 @@ __device__ __forceinline__ float half_reduce16(const float (&v)[16], int r)
     float d = (u1 ? c[1] : c[0]) + __shfl_xor(u1 ? c[0] : c[1], 2, 64);
     d += __shfl_xor(d, 1, 64);
     return d;
-}
-
-// GELU(v) = 0.5 v (1 + erf(v / sqrt 2)) (nn.GELU() default, multi_dino_attention.py:1098).  erfc(|x|) by Abramowitz &
-// Stegun 7.1.26 (absolute error <= 1.5e-7, i.e. fp32 rounding of an O(1) value), 1 + erf taken as erfc(|x|) on the
-// negative side so that nothing cancels: 14 instructions against ~40 of the library erff, which ran with the matrix
-// pipe idle.  -DWV_HF_EXACT_ERF restores erff.
-__device__ __forceinline__ float gelu_erf(float v)
-{
-#ifdef WV_HF_EXACT_ERF
-    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-#else
-    const float x = fabsf(v) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, x, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float erfc_abs = p * t * __expf(-x * x);
-    return 0.5f * v * (v >= 0.f ? 2.0f - erfc_abs : erfc_abs);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------ the kernel

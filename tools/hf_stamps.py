@@ -17,6 +17,7 @@ NAMES = ["feats -> LDS", "scores product", "softmax", "V product", "ctx mix", "o
 
 
 def main():
+    os.environ["WV_HEAD_FRONT"] = "1"
     lib = _lib.load()
     fn = lib.wv_debug_hf_stamps
     fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
