@@ -121,7 +121,7 @@ class Pipeline:
     def stage_rank(self, packed):
         from wvhash.parallel import sharded_hamming_topk
         idx, d, need = sharded_hamming_topk(packed, self.db_shard, NBITS, TOPK, N_DB, workspace=self.ws,
-                                            send_hint=self.send_hint, return_need=True)
+                                            send_hint=self.send_hint, return_need=True, want_dist=False)
         if need is not None:
             self.needs.append(need)
         return idx, d
@@ -224,8 +224,9 @@ def kernel_table(p, reps, swt_ms_live):
         rows.append(("wv_band_attn_pool[3 launches: fused front k_head_front (V, scores, softmax, out-proj, LN, MLP; fp32 "
                      "MFMA) + read-out GEMM + LN]", "mfma", Q * head_flops, st["head1"], how))
         rows.append(("wv_hash_tail", "hbm", Q * (EMBED * 4 + 8) + NBITS * EMBED * 4, st["tail1"], how))
-        rows.append(("wv_hamming_topk[k_rank_window 64b N=25000 k=5000]", "hbm",
-                     (Q + N_DB) * NBITS // 8 + Q * TOPK * 5, st["rank1"], how))
+        # the step ranks for mAP: lists only (4 bytes per entry), no distance row
+        rows.append(("wv_hamming_topk[k_rank_window 64b N=25000 k=5000, lists only]", "hbm",
+                     (Q + N_DB) * NBITS // 8 + Q * TOPK * 4, st["rank1"], how))
         rows.append(("wv_map_at_k", "hbm", Q * TOPK * 4 + (Q + N_DB) * 8 + Q * 8, st["map1"], how))
         from wvhash.transforms import swt2d
         bm = torch.empty((4, Q, 3, H, W), dtype=torch.float32, device=p.dev)

@@ -312,7 +312,7 @@ def evaluate_sharded(net, test_dataset, k=5000, epoch=None, batch_size=64, num_w
     else:
         rlp_all = rlp_local
     k_eff = min(int(k), n_db) if k is not None else n_db
-    idx, _ = sharded_hamming_topk(qp, rp, nbits, k_eff, n_db, group=group)
+    idx, _ = sharded_hamming_topk(qp, rp, nbits, k_eff, n_db, group=group, want_dist=False)
     # global row g of shard s sits at row s * per_db + (g - lo_s) of the gathered label table = g (shards are contiguous
     # slices of equal length per_db, the last one shorter): the gathered table is indexed by the global row directly
     ap, _ = H.map_at_k(idx, qlp, rlp_all)

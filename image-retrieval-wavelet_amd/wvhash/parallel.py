@@ -64,7 +64,7 @@ def _all_reduce(t, op, group):
 
 
 def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, workspace=None, trim=True,
-                         send_hint=None, return_need=False):
+                         send_hint=None, return_need=False, want_dist=True):
     """q_local: packed codes of THIS rank's queries [Ql, words]; db_shard: this rank's rows
     [lo:hi] of the packed database (tensor or PreparedDB).  Returns the global (idx int32 [Ql,k], dist uint8
     [Ql,k]) of the local queries.  Every rank must call with the same Ql.
@@ -78,10 +78,14 @@ def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, works
     send_hint (with trim): prefix length to exchange WITHOUT the host read -- for a steady stream of query batches
     (serving, bench.py) whose needed length is known from earlier batches.  The call then never synchronises with the
     host; the result is exact iff the returned `need` (device int32 [1], return_need=True) is <= send_hint, which
-    the caller checks whenever it next synchronises anyway (`exchange_ok`)."""
+    the caller checks whenever it next synchronises anyway (`exchange_ok`).
+
+    want_dist=False: the caller only needs the ranked lists (mAP does: calculate_maphashing, accuracy_calculator.py:183-231,
+    never looks at the distances once the order is known).  With one rank the distance row is then not written at all
+    (41 instead of 50 us at 2048 x 25,000, k = 5000); the merge of the multi-rank path writes it either way."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
-        out = H.hamming_topk(q_local, db_shard, nbits, k, workspace=workspace)
+        out = H.hamming_topk(q_local, db_shard, nbits, k, workspace=workspace, want_dist=want_dist)
         return (out[0], out[1], None) if return_need else out
     rank = dist.get_rank(group)
     Ql, words = q_local.shape
