@@ -21,6 +21,12 @@
 //     LDS) -- measured slower than QB = 1 at every shape, so only QB = 1 is instantiated;
 //   * k = 0 is a histogram-only mode (one count pass over all bins), rows16 output writes 16-bit local row numbers:
 //     the two steps of the sharded search (wv_hamming_hist, wv_hamming_topk_rows16).
+//   * optional: average precision of the list without ever writing it (wv_hamming_map_at_k).  calculate_maphashing
+//     (accuracy_calculator.py:183-231) returns one number per query; the list, 20 KB per query, was written to HBM only
+//     to be read back by the AP kernel, which then gathers 8-byte labels at random (the gather unit serves ~1 lane per
+//     clock: half of that kernel's time).  Here the labels come as a class-major bit matrix: the OR of the rows of the
+//     query's classes is its relevance bitmap (N bits, in LDS), and after placement the list in LDS is walked against
+//     the bitmap -- same thread <-> position mapping and summation order as k_map_at_k, bit-identical AP.
 // Covers databases (shards) of at most 32,768 rows -- C <= 128 items per thread, their distances cached in registers as
 // bytes; 16-bit item numbers and counters -- and k small enough for the LDS list; everything else stays on topk.hip's kernel.
 #include "common.hpp"
@@ -83,12 +89,25 @@ struct Rank2Lds {
     uint32_t *misc;      // [4]: group minimum etc.
 };
 
+// average precision instead of (or beside) the list: all pointers NULL = off
+struct Rank2Ap {
+    const uint32_t *cls;     // class-major label bit matrix [64][ceil(N / 32)] (rank2_labels_prepare)
+    const uint64_t *qlab;    // [Q] label word of every query
+    float *ap;               // [Q]
+    int32_t *nrel;           // [Q] relevant entries among the k (or NULL)
+};
+constexpr int kApRounds = 32;                // list positions per thread the AP walk keeps as bits: k <= 32 * TPQ
+
+// words of the relevance bitmap: one bit per database row
+__host__ __device__ inline int rank2_bitmap_words(int64_t N) { return (int)((N + 31) / 32); }
+
 template <int TPQ>
-__host__ __device__ inline size_t rank2_lds_bytes_per_query(int k)
+__host__ __device__ inline size_t rank2_lds_bytes_per_query(int k, int bm_words = 0)
 {
     size_t b = (size_t)kWinRows * (TPQ / 2) * 4;                 // table
     b += ((size_t)(k + TPQ) * 2 + 15) / 16 * 16;                 // stage
     b += (size_t)(kMaxBins2 + 1 + kWinBins + 4 + 3) / 4 * 4 * 4; // gbase, tot, misc
+    b += (size_t)bm_words * 4;                                   // relevance bitmap
     b = (b + 15) / 16 * 16;
     const size_t hist = (size_t)(kMaxBins2 + 1) * 17 * 4;        // histogram-only mode: [bins + 1][16] dwords + totals
     return b > hist ? b : (hist + 15) / 16 * 16;
@@ -201,13 +220,131 @@ __device__ __forceinline__ void rank2_hist_only(const uint32_t (&dc)[NC], int64_
     (void)N;
 }
 
+// Relevance bitmap of one query in LDS: bit (row) = the row's label word shares a bit with the query's
+// (label_comparison_fn, accuracy_calculator.py:31-37, on multi-hot words).  The labels come as a class-major bit matrix
+// cls[64][nw] (bit r of row c = row r carries class c: rank2_labels_prepare), so the bitmap is the OR of the matrix rows
+// of the query's classes -- a few 3 KB rows instead of all N label words (a pass over N x 8 bytes per query, the size of
+// the code image, cost as much as the distance pass: the texture path moves 64 bytes per clock and CU).
+template <int TPQ>
+__device__ __forceinline__ void rank2_relevance_bitmap(const uint32_t *__restrict__ cls, uint64_t ql, int nw, int t, uint32_t *bitmap)
+{
+    // A thread owns words t, t + TPQ, ... (at most 4: N <= 32768).  Per round four classes x four words = 16 loads are
+    // issued before the first is used: an L2 round trip costs ~4 k cycles under this kernel's load, a word-by-word,
+    // class-by-class chain of them was a third of the workgroup's time.
+    constexpr int WPT = 4;
+    uint32_t acc[WPT] = {0u, 0u, 0u, 0u};
+    int wi[WPT];
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) wi[i] = min(t + i * TPQ, nw - 1);
+    uint64_t m = ql;                                             // uniform: the loop runs on the scalar unit
+    while (m) {
+        const int c0 = __builtin_ctzll(m);
+        m &= m - 1;
+        const int c1 = m ? __builtin_ctzll(m) : c0;
+        m &= m - 1;
+        const int c2 = m ? __builtin_ctzll(m) : c0;
+        m &= m - 1;
+        const int c3 = m ? __builtin_ctzll(m) : c0;
+        m &= m - 1;
+        uint32_t v[4][WPT];
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            v[0][i] = cls[(size_t)c0 * nw + wi[i]];
+            v[1][i] = cls[(size_t)c1 * nw + wi[i]];
+            v[2][i] = cls[(size_t)c2 * nw + wi[i]];
+            v[3][i] = cls[(size_t)c3 * nw + wi[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) acc[i] |= (v[0][i] | v[1][i]) | (v[2][i] | v[3][i]);
+    }
+#pragma unroll
+    for (int i = 0; i < WPT; ++i)
+        if (t + i * TPQ < nw) bitmap[t + i * TPQ] = acc[i];
+    for (int w = t + WPT * TPQ; w < nw; w += TPQ) bitmap[w] = 0;   // not reached for N <= 32768 rows and TPQ = 256
+    // the caller's next group barrier (there are several before the list is walked) makes the bitmap visible
+}
+
+// AP of the list in LDS (k_map_at_k's arithmetic and order: position p = round * TPQ + t, the j-th hit adds the fp32
+// quotient j / (p + 1) to a double, waves summed in index order).  scratch: free LDS, (32 * NW + 2 * NW + 2) dwords.
+template <int TPQ>
+__device__ __forceinline__ void rank2_ap(const uint16_t *stage, const uint32_t *bitmap, uint32_t *scratch, int k, int t,
+                                         float *__restrict__ ap_out, int32_t *__restrict__ nrel_out)
+{
+    constexpr int NW = TPQ / 64;
+    const int lane = t & 63, wv = t >> 6;
+    const int R = (k + TPQ - 1) / TPQ;                           // <= kApRounds (host check)
+    uint32_t *cnt = scratch;                                     // [R][NW] hits of a wave in a round
+    double *wsum = reinterpret_cast<double *>(scratch + kApRounds * NW + (kApRounds * NW & 1));
+    // Eight rounds at a time, every LDS read of a batch issued before the first is used: with other workgroups' atomics
+    // queued at the LDS unit a read takes ~1k cycles, and a chain of dependent ones (list entry -> bitmap word, round
+    // after round) would pay that 2 R times.
+    uint32_t relbits = 0;
+    constexpr int CH = 8;
+    for (int r0 = 0; r0 < R; r0 += CH) {
+        uint32_t it[CH], wd[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) it[u] = stage[min((r0 + u) * TPQ + t, k - 1)];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) wd[u] = bitmap[it[u] >> 5];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int r = r0 + u;
+            const bool rel = r < R && r * TPQ + t < k && ((wd[u] >> (it[u] & 31)) & 1u);
+            relbits |= (rel ? 1u : 0u) << (r & 31);
+            const uint64_t m = __ballot(rel);
+            if (lane == 0 && r < R) cnt[r * NW + wv] = (uint32_t)__popcll(m);
+        }
+    }
+    group_sync<TPQ>();
+    uint32_t running = 0;
+    double acc = 0.0;
+    for (int r0 = 0; r0 < R; r0 += CH) {
+        uint32_t c[CH][NW];
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) c[u][w2] = cnt[min(r0 + u, R - 1) * NW + w2];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int r = r0 + u;
+            if (r < R) {                                          // uniform
+                uint32_t before = running, tot = 0;
+#pragma unroll
+                for (int w2 = 0; w2 < NW; ++w2) {
+                    before += w2 < wv ? c[u][w2] : 0u;
+                    tot += c[u][w2];
+                }
+                const bool rel = (relbits >> r) & 1u;
+                const uint64_t m = __ballot(rel);
+                if (rel) {
+                    const uint32_t j = before + (uint32_t)mbcnt(m) + 1;
+                    acc += (double)((float)j / (float)(r * TPQ + t + 1));
+                }
+                running += tot;
+            }
+        }
+    }
+    acc = wave_sum_f64(acc);
+    if (lane == 0) wsum[wv] = acc;
+    group_sync<TPQ>();
+    if (t == 0) {
+        double s = wsum[0];
+#pragma unroll
+        for (int w2 = 1; w2 < NW; ++w2) s += wsum[w2];
+        *ap_out = running ? (float)(s / (double)running) : 0.0f;
+        if (nrel_out) *nrel_out = (int32_t)running;
+    }
+}
+
 // Ranks ONE query from its cached distances.  Ends with a group barrier: the LDS region may be reused at once.
 // NC = distance-cache words (4 items each): items per thread C <= 4 * NC
-template <int TPQ, int NC>
+template <int TPQ, int NC, bool AP = false>
 __device__ __forceinline__ void rank2_one_query(const uint32_t (&dc)[NC], uint32_t dmin, int64_t N, int C,
                                                 int nbins, int k, int64_t idx_offset, int32_t *__restrict__ idx_out,
                                                 uint16_t *__restrict__ rows16_out, uint8_t *__restrict__ dist_out,
-                                                uint32_t *__restrict__ cum_out, uint8_t *lds_raw, int t)
+                                                uint32_t *__restrict__ cum_out, uint8_t *lds_raw, int t,
+                                                const uint32_t *__restrict__ cls = nullptr, uint64_t qlabel = 0,
+                                                float *__restrict__ ap_out = nullptr, int32_t *__restrict__ nrel_out = nullptr)
 {
     // k == 0: histogram only (cum_out), no list.  rows16_out: the list as 16-bit LOCAL row numbers instead of idx_out.
     constexpr int ROWB = TPQ * 2;                                // bytes per table row
@@ -219,9 +356,12 @@ __device__ __forceinline__ void rank2_one_query(const uint32_t (&dc)[NC], uint32
     L.gbase = reinterpret_cast<uint32_t *>(p);
     L.tot = L.gbase + kMaxBins2 + 1;
     L.misc = L.tot + kWinBins;
+    uint32_t *bitmap = L.misc + 4;                               // relevance of every item (AP only)
+    R2_STAMP_INIT;
+    if constexpr (AP) rank2_relevance_bitmap<TPQ>(cls, qlabel, rank2_bitmap_words(N), t, bitmap);
+    R2_STAMP(6);
     const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform
     constexpr int NW = TPQ / 64;                                 // waves per query
-    R2_STAMP_INIT;
     const int first = t * C;
     // smallest distance of the query = first bin of the first window
     dmin = wave_min_u32(dmin);
@@ -429,6 +569,8 @@ __device__ __forceinline__ void rank2_one_query(const uint32_t (&dc)[NC], uint32
         }
     }
     R2_STAMP(5);
+    if constexpr (AP) rank2_ap<TPQ>(L.stage, bitmap, L.table, k, t, ap_out, nrel_out);   // the count table is free by now
+    R2_STAMP(7);
     group_sync<TPQ>();                                            // the next query of the group reuses this LDS
 }
 
@@ -457,14 +599,41 @@ __global__ __launch_bounds__(256) void k_rank2_image(const uint64_t *__restrict_
     }
 }
 
+// Class-major label bit matrix: cls[c][w] bit j = row 32 w + j carries class c (bit c of its 64-bit label word).
+__global__ __launch_bounds__(256) void k_rank2_label_matrix(const uint64_t *__restrict__ dblab, uint32_t *__restrict__ cls, int64_t N, int nw)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one thread per (word, class), the class fastest
+    if (i >= (int64_t)nw * 64) return;
+    const int c = (int)(i & 63);
+    const int64_t w = i >> 6;
+    uint32_t word = 0;
+    for (int j = 0; j < 32; ++j) {
+        const int64_t r = w * 32 + j;
+        if (r < N) word |= (uint32_t)((dblab[r] >> c) & 1ull) << j;
+    }
+    cls[(size_t)c * nw + w] = word;
+}
+
+size_t rank2_labels_bytes(int64_t N) { return (size_t)64 * rank2_bitmap_words(N) * sizeof(uint32_t); }
+
+int rank2_labels_prepare(const uint64_t *dblab, void *cls, int64_t N, hipStream_t st)
+{
+    const int nw = rank2_bitmap_words(N);
+    hipLaunchKernelGGL(k_rank2_label_matrix, dim3((unsigned)ceil_div((int64_t)nw * 64, 256)), dim3(256), 0, st, dblab,
+                       (uint32_t *)cls, N, nw);
+    WV_CHECK_LAUNCH("k_rank2_label_matrix");
+    return WV_OK;
+}
+
 // minimum waves per SIMD the register allocation has to leave room for (the LDS footprint admits at least as many)
 constexpr int rank2_min_waves(int nc, int qb) { return nc * qb <= 8 ? 7 : (nc * qb <= 16 ? 6 : (nc * qb <= 25 ? WV_R2_W25 : (nc * qb <= 32 ? 4 : 3))); }
 
-template <int WORDS, int TPQ, int NC, int QB>
+// AP = true: the instantiation behind wv_hamming_map_at_k (its own kernels: the plain ranking keeps its registers)
+template <int WORDS, int TPQ, int NC, int QB, bool AP>
 __global__ __launch_bounds__(256, rank2_min_waves(NC, QB)) void k_rank_window(const uint64_t *__restrict__ q, const uint4 *__restrict__ img,
                                                      int32_t *__restrict__ idx, uint16_t *__restrict__ rows16,
                                                      uint8_t *__restrict__ dist, int Q, int64_t N, int C, int nbins, int k,
-                                                     int64_t idx_offset, uint32_t *__restrict__ cum, int lds_per_group)
+                                                     int64_t idx_offset, uint32_t *__restrict__ cum, int lds_per_group, Rank2Ap apx)
 {
     extern __shared__ uint4 lds4[];
     constexpr int GPW = 256 / TPQ;                              // query groups per workgroup
@@ -491,10 +660,21 @@ __global__ __launch_bounds__(256, rank2_min_waves(NC, QB)) void k_rank_window(co
         const int qi = q0 + qq;
         if (qi < Q && k == 0)                                    // histogram only
             rank2_hist_only<TPQ, NC>(dc[qq], N, C, nbins, cum + (int64_t)qi * (nbins + 1), lds, t);
-        else if (qi < Q)                                         // uniform over the group (and over the workgroup when TPQ = 256)
-            rank2_one_query<TPQ, NC>(dc[qq], dmin[qq], N, C, nbins, k, idx_offset, idx ? idx + (int64_t)qi * k : nullptr,
-                                     rows16 ? rows16 + (int64_t)qi * k : nullptr, dist ? dist + (int64_t)qi * k : nullptr,
-                                     cum ? cum + (int64_t)qi * (nbins + 1) : nullptr, lds, t);
+        else if (qi < Q) {                                       // uniform over the group (and over the workgroup when TPQ = 256)
+            if constexpr (AP) {
+                const uint64_t lw = apx.qlab[qi];
+                const uint64_t ql = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(lw >> 32)) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)lw);
+                rank2_one_query<TPQ, NC, true>(dc[qq], dmin[qq], N, C, nbins, k, idx_offset, idx ? idx + (int64_t)qi * k : nullptr,
+                                               rows16 ? rows16 + (int64_t)qi * k : nullptr, dist ? dist + (int64_t)qi * k : nullptr,
+                                               cum ? cum + (int64_t)qi * (nbins + 1) : nullptr, lds, t, apx.cls, ql,
+                                               apx.ap + qi, apx.nrel ? apx.nrel + qi : nullptr);
+            } else {
+                rank2_one_query<TPQ, NC>(dc[qq], dmin[qq], N, C, nbins, k, idx_offset, idx ? idx + (int64_t)qi * k : nullptr,
+                                         rows16 ? rows16 + (int64_t)qi * k : nullptr, dist ? dist + (int64_t)qi * k : nullptr,
+                                         cum ? cum + (int64_t)qi * (nbins + 1) : nullptr, lds, t);
+            }
+        }
     }
 }
 
@@ -535,39 +715,39 @@ int rank2_prepare(const uint64_t *db, void *img, int64_t N, int words, int tpq, 
 
 template <int WORDS, int TPQ, int NC, int QB>
 static int launch_rank2_qb(const uint64_t *q, const void *img, int32_t *idx, uint16_t *rows16, uint8_t *dist, int Q, int64_t N,
-                           int C, int nbins, int k, int64_t idx_offset, uint32_t *cum, hipStream_t st)
+                           int C, int nbins, int k, int64_t idx_offset, uint32_t *cum, const Rank2Ap &apx, hipStream_t st)
 {
     constexpr int GPW = 256 / TPQ;
-    const size_t per_g = rank2_lds_bytes_per_query<TPQ>(k), lds = per_g * GPW;
-    auto kern = k_rank_window<WORDS, TPQ, NC, QB>;
+    const size_t per_g = rank2_lds_bytes_per_query<TPQ>(k, apx.ap ? rank2_bitmap_words(N) : 0), lds = per_g * GPW;
+    auto kern = apx.ap ? k_rank_window<WORDS, TPQ, NC, QB, true> : k_rank_window<WORDS, TPQ, NC, QB, false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) WV_FAIL(WV_EHIP, "rank_window: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(Q, GPW * QB)), dim3(256), lds, st, q, (const uint4 *)img, idx, rows16, dist,
-                       Q, N, C, nbins, k, idx_offset, cum, (int)per_g);
+                       Q, N, C, nbins, k, idx_offset, cum, (int)per_g, apx);
     WV_CHECK_LAUNCH("k_rank_window");
     return WV_OK;
 }
 
 template <int WORDS, int TPQ, int NC, int QBMAX>
 static int launch_rank2_nc(const uint64_t *q, const void *img, int32_t *idx, uint16_t *rows16, uint8_t *dist, int Q, int64_t N,
-                           int C, int nbins, int k, int64_t idx_offset, uint32_t *cum, hipStream_t st)
+                           int C, int nbins, int k, int64_t idx_offset, uint32_t *cum, const Rank2Ap &apx, hipStream_t st)
 {
     // Sharing one pass over the image between QBMAX queries of a group (ranked one after the other) was measured on
     // MI355X and is slower at every shape tried (c1: 66 vs 50 us; 16384 x 3125: 176 vs 145 us): the registers of the
     // extra distance caches cost more occupancy than the saved L2 reads are worth.  The kernel keeps the template
     // parameter; only QB = 1 is instantiated.
     (void)QBMAX;
-    return launch_rank2_qb<WORDS, TPQ, NC, 1>(q, img, idx, rows16, dist, Q, N, C, nbins, k, idx_offset, cum, st);
+    return launch_rank2_qb<WORDS, TPQ, NC, 1>(q, img, idx, rows16, dist, Q, N, C, nbins, k, idx_offset, cum, apx, st);
 }
 
 template <int WORDS, int TPQ>
 static int launch_rank2_t(const uint64_t *q, const void *img, int32_t *idx, uint16_t *rows16, uint8_t *dist, int Q, int64_t N,
-                          int nbins, int k, int64_t idx_offset, uint32_t *cum, hipStream_t st)
+                          int nbins, int k, int64_t idx_offset, uint32_t *cum, const Rank2Ap &apx, hipStream_t st)
 {
     const int C = (int)ceil_div(N, TPQ);
-#define WV_R2(NCW, QBM) return launch_rank2_nc<WORDS, TPQ, NCW, QBM>(q, img, idx, rows16, dist, Q, N, C, nbins, k, idx_offset, cum, st)
+#define WV_R2(NCW, QBM) return launch_rank2_nc<WORDS, TPQ, NCW, QBM>(q, img, idx, rows16, dist, Q, N, C, nbins, k, idx_offset, cum, apx, st)
     if (C <= 16) WV_R2(4, 8);
     if (C <= 32) WV_R2(8, 4);
     if (C <= 64) WV_R2(16, 2);
@@ -583,15 +763,23 @@ static int launch_rank2_t(const uint64_t *q, const void *img, int32_t *idx, uint
 // img must be the image for `tpq` threads per query (rank2_prepare)
 // idx (int32 global indices) or rows16 (16-bit local row numbers) receives the list; k == 0: histogram only
 int rank2_launch(const uint64_t *q, const void *img, int32_t *idx, uint16_t *rows16, uint8_t *dist, int Q, int64_t N, int nbits,
-                 int k, int64_t idx_offset, uint32_t *cum, int tpq, hipStream_t st)
+                 int k, int64_t idx_offset, uint32_t *cum, int tpq, hipStream_t st, const void *lab_img, const uint64_t *qlab,
+                 float *ap, int32_t *nrel)
 {
     const int nbins = nbits + 1, words = (nbits + 63) / 64;
-    if (words == 1) {
-        if (tpq == 64) return launch_rank2_t<1, 64>(q, img, idx, rows16, dist, Q, N, nbins, k, idx_offset, cum, st);
-        return launch_rank2_t<1, 256>(q, img, idx, rows16, dist, Q, N, nbins, k, idx_offset, cum, st);
+    Rank2Ap apx{reinterpret_cast<const uint32_t *>(lab_img), qlab, ap, nrel};
+    if (ap) {
+        if (!lab_img || !qlab || k < 1 || k > kApRounds * tpq) return 1;                     // the AP walk keeps <= 32 positions per thread
+        const size_t per_g = tpq == 64 ? 4 * rank2_lds_bytes_per_query<64>(k, rank2_bitmap_words(N))
+                                       : rank2_lds_bytes_per_query<256>(k, rank2_bitmap_words(N));
+        if (per_g > 100 * 1024) return 1;
     }
-    if (tpq == 64) return launch_rank2_t<2, 64>(q, img, idx, rows16, dist, Q, N, nbins, k, idx_offset, cum, st);
-    return launch_rank2_t<2, 256>(q, img, idx, rows16, dist, Q, N, nbins, k, idx_offset, cum, st);
+    if (words == 1) {
+        if (tpq == 64) return launch_rank2_t<1, 64>(q, img, idx, rows16, dist, Q, N, nbins, k, idx_offset, cum, apx, st);
+        return launch_rank2_t<1, 256>(q, img, idx, rows16, dist, Q, N, nbins, k, idx_offset, cum, apx, st);
+    }
+    if (tpq == 64) return launch_rank2_t<2, 64>(q, img, idx, rows16, dist, Q, N, nbins, k, idx_offset, cum, apx, st);
+    return launch_rank2_t<2, 256>(q, img, idx, rows16, dist, Q, N, nbins, k, idx_offset, cum, apx, st);
 }
 
 }  // namespace wv

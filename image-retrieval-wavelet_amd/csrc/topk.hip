@@ -25,8 +25,12 @@ constexpr int kTopkThreads = 256;
 int rank2_tpq(int Q, int64_t N, int k);
 size_t rank2_image_bytes(int64_t N, int words, int tpq);
 int rank2_prepare(const uint64_t *db, void *img, int64_t N, int words, int tpq, hipStream_t st);
+size_t rank2_labels_bytes(int64_t N);
+int rank2_labels_prepare(const uint64_t *dblab, void *cls, int64_t N, hipStream_t st);
+// lab_img (the class-major label bit matrix) / qlab / ap / nrel: average precision of the list (wv_hamming_map_at_k); all NULL otherwise
 int rank2_launch(const uint64_t *q, const void *img, int32_t *idx, uint16_t *rows16, uint8_t *dist, int Q, int64_t N, int nbits,
-                 int k, int64_t idx_offset, uint32_t *cum, int tpq, hipStream_t st);
+                 int k, int64_t idx_offset, uint32_t *cum, int tpq, hipStream_t st, const void *lab_img = nullptr,
+                 const uint64_t *qlab = nullptr, float *ap = nullptr, int32_t *nrel = nullptr);
 // the one-wave-per-query image exists for databases (shards) of at most this many rows
 constexpr int64_t kImg64MaxRows = 64 * 64;
 // images of the windowed kernel exist for databases it can take at all (16-bit item numbers, <= 128 items per thread)
@@ -944,6 +948,44 @@ extern "C" int wv_hamming_topk_ex(const uint64_t *q, const uint64_t *db, const v
     }
     if (words == 1) return launch_topk<1>(q, db, dbT, idx, dist, Q, N, nbits, k, idx_offset, workspace, st, cum);
     return launch_topk<2>(q, db, dbT, idx, dist, Q, N, nbits, k, idx_offset, workspace, st, cum);
+}
+
+// ---------------------------------------------------------------------------------- mAP without the lists
+extern "C" size_t wv_rank_labels_prepared_bytes(int64_t N)
+{
+    if (N < 1 || N > kImg256MaxRows) return 0;
+    return rank2_labels_bytes(N);
+}
+
+extern "C" int wv_rank_labels_prepare(const uint64_t *dblab, int64_t N, void *prepared_labels, size_t prepared_bytes, void *stream)
+{
+    WV_REQUIRE(dblab && prepared_labels, "rank_labels_prepare: null buffer");
+    const size_t need = wv_rank_labels_prepared_bytes(N);
+    if (!need) WV_FAIL(WV_ENOTSUP, "rank_labels_prepare: %lld rows are outside the windowed ranking kernel (<= 32768)", (long long)N);
+    if (prepared_bytes < need) WV_FAIL(WV_ENOMEM, "rank_labels_prepare: buffer %zu < %zu bytes", prepared_bytes, need);
+    return rank2_labels_prepare(dblab, prepared_labels, N, (hipStream_t)stream);
+}
+
+extern "C" int wv_hamming_map_at_k(const uint64_t *q, const void *prepared, const void *prepared_labels, const uint64_t *qlab,
+                                   int Q, int64_t N, int nbits, int k, float *ap, int32_t *nrel, void *stream)
+{
+    WV_REQUIRE(q && prepared && prepared_labels && qlab && ap, "hamming_map_at_k: null buffer");
+    WV_REQUIRE(Q >= 0 && N >= 1, "hamming_map_at_k: bad shape Q=%d N=%lld", Q, (long long)N);
+    WV_REQUIRE(nbits >= 1 && nbits <= 128, "hamming_map_at_k: nbits=%d (supported: 1..128)", nbits);
+    WV_REQUIRE(k >= 1 && k <= N, "hamming_map_at_k: k=%d must be in [1, N=%lld]", k, (long long)N);
+    if (Q == 0) return WV_OK;
+    const int words = (nbits + 63) / 64;
+    int tpq = rank2_tpq(Q, N, k);
+    if (tpq == 64 && k > 32 * 64 && N <= kImg256MaxRows) tpq = 256;      // the AP walk keeps 32 list positions per thread
+    if (!tpq || N > kImg256MaxRows || (tpq == 64 && N > kImg64MaxRows))
+        WV_FAIL(WV_ENOTSUP, "hamming_map_at_k: %lld rows / k=%d are outside the windowed kernel (wv_hamming_topk + wv_map_at_k)",
+                (long long)N, k);
+    const char *base = (const char *)prepared + align_up((int64_t)dist_prepared_bytes(N, words), 256);
+    const void *img = base + (tpq == 256 ? r2_off256(N, words) : r2_off64(N, words));
+    const int rc = rank2_launch(q, img, nullptr, nullptr, nullptr, Q, N, nbits, k, 0, nullptr, tpq, (hipStream_t)stream,
+                                prepared_labels, qlab, ap, nrel);
+    if (rc > 0) WV_FAIL(WV_ENOTSUP, "hamming_map_at_k: k=%d is outside the fused kernel (wv_hamming_topk + wv_map_at_k)", k);
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------- sharded search, two steps

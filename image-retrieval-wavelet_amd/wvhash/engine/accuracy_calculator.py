@@ -212,8 +212,18 @@ class CustomCalculator(object):
         num_query = query.shape[0]
         if num_query == 0:
             raise ZeroDivisionError("calculate_maphashing: no queries")
-        idx = self._ranked_lists(query, reference, topk)
-        ap, _ = self._average_precisions(idx, query_labels, reference_labels, k=topk)
+        ap = None
+        if self.rank_cache is None:
+            # one k, nothing to share: ranking and AP in one kernel, the lists never leave the GPU's LDS
+            # (same numbers as the two steps below; None = shape outside the fused kernel)
+            qlp, rlp = self._packed_labels(query_labels, reference_labels)
+            fused = H.hamming_map_at_k(H.pack_codes(query), H.PreparedDB(H.pack_codes(reference), reference.shape[1]),
+                                       H.PreparedLabels(rlp), qlp, reference.shape[1], topk) if rlp.shape[1] == 1 else None
+            if fused is not None:
+                ap = fused[0]
+        if ap is None:
+            idx = self._ranked_lists(query, reference, topk)
+            ap, _ = self._average_precisions(idx, query_labels, reference_labels, k=topk)
         result = ap.double().sum().item() / num_query
         if return_per_query:
             return result, ap

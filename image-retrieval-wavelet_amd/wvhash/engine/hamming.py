@@ -296,6 +296,53 @@ def map_at_k(idx, qlab_packed, dblab_packed, k=None):
     return ap, nrel
 
 
+class PreparedLabels:
+    """The database rows' packed label words laid out for the fused ranking + AP kernel (wv_rank_labels_prepare): one
+    64-bit multi-hot word per row, databases of at most 32,768 rows.  `ok` is False for anything else -- the caller then
+    ranks and evaluates in two steps."""
+
+    def __init__(self, dblab_packed):
+        lib = _lib.require_gpu()
+        if dblab_packed.dim() != 2 or dblab_packed.dtype != torch.int64:
+            raise ValueError("PreparedLabels: expected packed int64 label words [N, words] (see pack_codes)")
+        self.packed = dblab_packed.contiguous()
+        self.N, self.words = self.packed.shape
+        nbytes = lib.wv_rank_labels_prepared_bytes(self.N) if self.words == 1 and self.N else 0
+        self.ok = nbytes > 0
+        self.blob = None
+        if self.ok:
+            self.blob = torch.empty(nbytes, dtype=torch.uint8, device=self.packed.device)
+            with torch.cuda.device(self.packed.device):
+                rc = lib.wv_rank_labels_prepare(_lib.ptr(self.packed), self.N, _lib.ptr(self.blob), ctypes.c_size_t(nbytes),
+                                                _lib.stream_ptr())
+                _lib.check(rc, "wv_rank_labels_prepare")
+
+
+def hamming_map_at_k(q_packed, db, labels, qlab_packed, nbits, k):
+    """mAP@k ingredients straight from the codes -> (ap float32 [Q], nrel int32 [Q]), or None when the shape is outside
+    the fused kernel (the caller then runs hamming_topk + map_at_k, which return exactly the same numbers).
+    db: PreparedDB; labels: PreparedLabels of the same rows; qlab_packed: int64 [Q, 1]."""
+    lib = _lib.require_gpu()
+    if not isinstance(db, PreparedDB) or not isinstance(labels, PreparedLabels):
+        raise TypeError("hamming_map_at_k: needs a PreparedDB and PreparedLabels")
+    Q, words = q_packed.shape
+    if words != db.words or labels.N != db.N:
+        raise ValueError("hamming_map_at_k: query / database / label shapes disagree")
+    if not labels.ok or qlab_packed.shape[1] != 1 or nbits > 128 or not 1 <= k <= db.N:
+        return None
+    ap = torch.empty(Q, dtype=torch.float32, device=q_packed.device)
+    nrel = torch.empty(Q, dtype=torch.int32, device=q_packed.device)
+    if Q:
+        with torch.cuda.device(q_packed.device):
+            rc = lib.wv_hamming_map_at_k(_lib.ptr(q_packed.contiguous()), _lib.ptr(db.blob), _lib.ptr(labels.blob),
+                                         _lib.ptr(qlab_packed.contiguous()), Q, db.N, nbits, k, _lib.ptr(ap), _lib.ptr(nrel),
+                                         _lib.stream_ptr())
+            if rc == -95:      # WV_ENOTSUP
+                return None
+            _lib.check(rc, "wv_hamming_map_at_k")
+    return ap, nrel
+
+
 def hit_prefix(idx, qlab_packed, dblab_packed):
     """hits[q, p] = number of relevant entries among idx[q, :p+1] (uint32 counts as int32 tensor [Q, k])."""
     lib = _lib.require_gpu()

@@ -179,6 +179,21 @@ int wv_hamming_topk_ex(const uint64_t *q, const uint64_t *db, const void *prepar
                        uint32_t *cum, int Q, int64_t N, int nbits, int k, int64_t idx_offset, void *workspace,
                        size_t workspace_bytes, void *stream);
 
+/* mAP@k of every query straight from the codes -- what calculate_maphashing (accuracy_calculator.py:183-231) returns -- without
+ * writing the ranked lists: the windowed ranking kernel builds the list in LDS as wv_hamming_topk does (ascending distance,
+ * ties by ascending row) and evaluates it there against a relevance bitmap of the query made from the rows' label words
+ * (one 64-bit multi-hot word per row: label_comparison_fn, :31-37).  ap float32 [Q] and nrel int32 [Q] (or NULL) are exactly
+ * what wv_map_at_k returns for wv_hamming_topk's list (same summation order; bit-identical at 256 threads per query).
+ *   prepared         wv_db_prepare's blob of the database codes
+ *   prepared_labels  wv_rank_labels_prepare's class-major bit matrix of the rows' label words
+ *                    (wv_rank_labels_prepared_bytes(N) bytes; 0 = N is outside the windowed kernel)
+ * Returns WV_ENOTSUP for shapes outside the fused kernel (more than 32,768 rows, k > 8,192, ...): the caller then runs
+ * wv_hamming_topk + wv_map_at_k. */
+size_t wv_rank_labels_prepared_bytes(int64_t N);
+int wv_rank_labels_prepare(const uint64_t *dblab, int64_t N, void *prepared_labels, size_t prepared_bytes, void *stream);
+int wv_hamming_map_at_k(const uint64_t *q, const void *prepared, const void *prepared_labels, const uint64_t *qlab, int Q,
+                        int64_t N, int nbits, int k, float *ap, int32_t *nrel, void *stream);
+
 /* The two steps of a row-sharded search (wvhash/parallel.py; the role of faiss' shard search + host merge at
  * get_knn.py:41-44) on one shard of at most 32,768 rows:
  *   wv_hamming_hist        only the cumulative distance histogram of every query, cum uint32 [Q][nbits + 2] as above -- no

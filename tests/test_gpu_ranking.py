@@ -550,3 +550,55 @@ def test_ap_of_list_prefixes_equals_ap_of_shorter_lists(Q, N, k, Lc):
         assert torch.equal(ap_prefix, ap_short) and torch.equal(n_prefix, n_short)
     _, ap_ref = ranking.calculate_maphashing(q[:12], ql[:12], r, rl, k, stable=True, return_per_query=True)
     np.testing.assert_allclose(H.map_at_k(idx, qlp, rlp)[0][:12].cpu().numpy(), ap_ref, atol=AP_TOL)
+
+
+@pytest.mark.parametrize("variant", [None, "256", "64"])
+@pytest.mark.parametrize("Q,N,nbits,k,Lc,spread", [(2048, 25000, 64, 5000, 38, False), (37, 3000, 64, 2500, 24, True),
+                                                   (5, 3000, 128, 3000, 64, True), (33, 1000, 64, 37, 5, True),
+                                                   (6, 257, 32, 257, 1, True), (4100, 700, 64, 200, 38, False),
+                                                   (11, 32768, 64, 8192, 38, False), (3, 4096, 16, 2048, 10, False)])
+def test_fused_map_at_k_equals_ranking_then_ap(monkeypatch, variant, Q, N, nbits, k, Lc, spread):
+    """wv_hamming_map_at_k (list built and evaluated in LDS, never written) against wv_hamming_topk + wv_map_at_k: AP and
+    hit counts of every query.  256 threads per query use the AP kernel's summation order -- bit-identical; one wave per
+    query sums in another order (fp64 partial sums: equal after the final fp32 rounding up to one ulp)."""
+    if variant is not None:
+        monkeypatch.setenv("WV_TOPK_V2", variant)
+    ql, rl = synth.multi_hot_labels(Q, Lc, 0.12, 11), synth.multi_hot_labels(N, Lc, 0.12, 12)
+    if spread:
+        q, r = _spread_codes(Q, N, nbits, seed=N + nbits)
+    else:
+        q, r = synth.structured_codes(ql, nbits, 3, 4), synth.structured_codes(rl, nbits, 3, 5)
+    qp, prep = H.pack_codes(q.cuda()), H.PreparedDB(H.pack_codes(r.cuda()), nbits)
+    qlp, rlp = H.pack_labels(ql.cuda()), H.pack_labels(rl.cuda())
+    labels = H.PreparedLabels(rlp)
+    assert labels.ok
+    fused = H.hamming_map_at_k(qp, prep, labels, qlp, nbits, k)
+    idx, _ = H.hamming_topk(qp, prep, nbits, k, want_dist=False)
+    ap_ref, nrel_ref = H.map_at_k(idx, qlp, rlp)
+    if fused is None:                                            # outside the fused kernel: must be one of the stated limits
+        tpq = 64 if variant == "64" else 256
+        assert k > 32 * tpq or (variant == "64" and N > 4096)
+        return
+    ap, nrel = fused
+    assert torch.equal(nrel, nrel_ref)
+    if variant == "64" or (variant is None and N <= 4096 and Q >= 4096):
+        assert (ap - ap_ref).abs().max().item() <= 1.2e-7
+    else:
+        assert torch.equal(ap, ap_ref)
+    # and against the oracle's AP on a few queries
+    ref_idx, _ = ranking.hamming_topk_stable(q[:8], r, k)
+    for i in range(min(Q, 8)):
+        rel = ((rl[ref_idx[i]] * ql[i]).sum(1) > 0).double()
+        hits = rel.cumsum(0)
+        want = float((rel * hits / torch.arange(1, k + 1).double()).sum() / rel.sum()) if rel.sum() > 0 else 0.0
+        assert abs(float(ap[i]) - want) < 1e-6
+
+
+def test_fused_map_at_k_refuses_what_it_cannot_do():
+    q, r = synth.random_codes(4, 300, 64, seed=1)
+    qp, prep = H.pack_codes(q.cuda()), H.PreparedDB(H.pack_codes(r.cuda()), 64)
+    wide = H.PreparedLabels(H.pack_labels(synth.multi_hot_labels(300, 100, 0.1, 1).cuda()))      # two label words per row
+    assert not wide.ok
+    assert H.hamming_map_at_k(qp, prep, wide, H.pack_labels(synth.multi_hot_labels(4, 100, 0.1, 2).cuda()), 64, 10) is None
+    big = H.PreparedLabels(torch.zeros((40000, 1), dtype=torch.int64, device="cuda"))               # more rows than the kernel takes
+    assert not big.ok
