@@ -654,6 +654,81 @@ __global__ __launch_bounds__(256) void k_hash_tail16(const float *__restrict__ f
     }
 }
 
+// Matrix-core form of the tail for E % 32 == 0: one workgroup per (32 samples, 32 bits), the contraction cut into four
+// k ranges (one per wave; partial tiles summed in wave order through LDS -- a fixed order, so a sample's logits do not
+// depend on the batch it arrives in).  Operands go global -> registers in the MFMA layout (lane (r, h): row r, k in
+// [8c + 4h, 8c + 4h + 4)), every load of a wave in flight at once.  The 16-samples-per-workgroup VALU kernel above spends
+// most of its 18.6 us transposing the hash matrix into LDS in every workgroup.
+__global__ __launch_bounds__(256) void k_hash_tail_mfma(const float *__restrict__ fused, int B, int E,
+                                                        const float *__restrict__ hw, const float *__restrict__ hb,
+                                                        const float *__restrict__ bn_w, const float *__restrict__ bn_b,
+                                                        const float *__restrict__ bn_mean,
+                                                        const float *__restrict__ bn_var, float eps, int nbits,
+                                                        float *__restrict__ logits_out, float *__restrict__ codes_out,
+                                                        uint64_t *__restrict__ packed_out)
+{
+    __shared__ float part[4][16][64];                          // [wave][accumulator element][lane]
+    const int lane = lane_id(), wv = wave_id(), r = lane & 31, h = lane >> 5;
+    const int b0 = blockIdx.x * 32, n = blockIdx.y;             // samples b0 .. b0+31, bits 32n .. 32n+31
+    const int cpw = E / 32;                                     // k-chunks of 8 per wave
+    const float *arow = fused + (size_t)min(b0 + r, B - 1) * E + (size_t)wv * cpw * 8 + 4 * h;
+    const float *brow = hw + (size_t)min(n * 32 + r, nbits - 1) * E + (size_t)wv * cpw * 8 + 4 * h;
+    f32x16 acc[2];                                              // even / odd chunks: two independent chains
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    constexpr int CB = 12;                                      // chunks per batch of loads: all of E = 384 in flight at once
+    for (int c0 = 0; c0 < cpw; c0 += CB) {
+        f32x4 av[CB], bv[CB];
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+            const int c = min(c0 + u, cpw - 1);
+            av[u] = *reinterpret_cast<const f32x4 *>(arow + 8 * c);
+            bv[u] = *reinterpret_cast<const f32x4 *>(brow + 8 * c);
+        }
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+            if (c0 + u < cpw) {                                 // uniform
+                acc[u & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].x, acc[u & 1], 0, 0, 0);
+                acc[u & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].y, acc[u & 1], 0, 0, 0);
+                acc[u & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, bv[u].z, acc[u & 1], 0, 0, 0);
+                acc[u & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].w, bv[u].w, acc[u & 1], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) part[wv][e][lane] = acc[0][e] + acc[1][e];
+    __syncthreads();
+    // wave w finishes accumulator elements 4w .. 4w+3: sample row 8*(e>>2) + 4h + (e&3), bit 32n + r
+    const int words = (nbits + 63) / 64;
+    const int j = 32 * n + r;
+    const bool valid = j < nbits;
+    float bias = 0.f, mean = 0.f, scale = 1.f, gain = 1.f, shift = 0.f;
+    if (valid) {
+        bias = hb ? hb[j] : 0.f;
+        if (bn_w) { mean = bn_mean[j]; scale = sqrtf(bn_var[j] + eps); gain = bn_w[j]; shift = bn_b[j]; }
+    }
+#pragma unroll
+    for (int ee = 0; ee < 4; ++ee) {
+        const int e = 4 * wv + ee;
+        const int b = b0 + 8 * (e >> 2) + 4 * h + (e & 3);
+        float v = ((part[0][e][lane] + part[1][e][lane]) + part[2][e][lane]) + part[3][e][lane];
+        v += bias;
+        if (bn_w) v = (v - mean) / scale * gain + shift;
+        if (valid && b < B) {
+            if (logits_out) logits_out[(size_t)b * nbits + j] = v;
+            if (codes_out) codes_out[(size_t)b * nbits + j] = v > 0.f ? 1.f : (v < 0.f ? -1.f : (v == 0.f ? 0.f : v));
+        }
+        const uint64_t bal = __ballot(valid && v > 0.f);        // low half: the sample of lanes 0-31, high half: of lanes 32-63
+        if (packed_out && r == 0 && b < B)                      // this workgroup's 32 bits = one half of a packed word
+            reinterpret_cast<uint32_t *>(packed_out)[((size_t)b * words + (n >> 1)) * 2 + (n & 1)] = (uint32_t)(bal >> (32 * h));
+    }
+    // an odd number of 32-bit blocks: the upper half of the last word is nobody's -- zero it
+    if (packed_out && n == (int)gridDim.y - 1 && (gridDim.y & 1) && wv == 0 && lane < 32 && b0 + lane < B)
+        reinterpret_cast<uint32_t *>(packed_out)[((size_t)(b0 + lane) * words + (n >> 1)) * 2 + 1] = 0u;
+}
+
 template <int BM, int BN, int EPI>
 static void launch_gemm_lds(const float *A, const float *W, const float *bias, const float *R, int rmod, float *C,
                             int M, int N, int K, hipStream_t st)
@@ -878,7 +953,13 @@ extern "C" int wv_hash_tail(const float *fused, int B, int E, const float *hash_
     WV_REQUIRE(E * sizeof(float) <= 48 * 1024, "hash_tail: E=%d too large", E);
     if (B == 0) return WV_OK;
     const size_t lds16 = ((size_t)4 * E * 4 + (size_t)E * 65) * sizeof(float);
-    if (lds16 <= (size_t)kMaxLdsBytes - 1024 && B >= 64 && !getenv("WV_HASH_TAIL_SIMPLE")) {
+    const char *pin = getenv("WV_HASH_TAIL");                   // "simple" / "valu16" / "mfma" pin a kernel (tests, A/B runs)
+    const bool simple = getenv("WV_HASH_TAIL_SIMPLE") || (pin && !strcmp(pin, "simple"));
+    if (!simple && !(pin && !strcmp(pin, "valu16")) && E % 32 == 0 && (B >= 32 || (pin && !strcmp(pin, "mfma")))) {
+        const dim3 grid((unsigned)ceil_div(B, 32), (unsigned)ceil_div(nbits, 32));
+        hipLaunchKernelGGL(k_hash_tail_mfma, grid, dim3(256), 0, (hipStream_t)stream, fused, B, E, hash_w, hash_b, bn_w, bn_b,
+                           bn_mean, bn_var, bn_eps, nbits, logits_out, codes_out, packed_out);
+    } else if (lds16 <= (size_t)kMaxLdsBytes - 1024 && B >= 64 && !simple) {
         if (lds16 > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_hash_tail16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
         hipLaunchKernelGGL(k_hash_tail16, dim3((unsigned)ceil_div(B, 16)), dim3(256), lds16, (hipStream_t)stream, fused, B,

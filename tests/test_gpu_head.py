@@ -187,10 +187,11 @@ def test_model_classes_end_to_end_with_stub_backbone():
 
 
 @pytest.mark.parametrize("B,nbits,with_bn", [(64, 64, True), (301, 64, True), (2048, 64, True), (130, 128, False), (77, 48, True)])
-def test_hash_tail_batched_kernel_is_bit_identical_to_per_sample_kernel(B, nbits, with_bn):
-    """k_hash_tail16 (16 samples per workgroup, LDS-staged weights) runs the same fmaf chain per logit as the
-    per-sample kernel: logits, codes and packed words must be identical bit for bit."""
-    import os
+def test_hash_tail_kernels_agree_and_do_not_depend_on_the_batch(B, nbits, with_bn, monkeypatch):
+    """Three kernels behind wv_hash_tail: per sample (fmaf chain), 16 samples per workgroup on the VALU (the same chain:
+    bit-identical to it), and the matrix-core one (32 samples per workgroup, four k ranges summed in a fixed order: other
+    rounding, within 1e-5 of the chain; codes equal wherever the logit is not within 1e-4 of zero).  Whatever the kernel,
+    a sample's logits must not depend on the batch it arrives in."""
     torch.manual_seed(B + nbits)
     fc = torch.nn.Linear(384, nbits, bias=not with_bn).cuda().eval()
     bn = torch.nn.BatchNorm1d(nbits).cuda().eval() if with_bn else torch.nn.Identity()
@@ -198,14 +199,27 @@ def test_hash_tail_batched_kernel_is_bit_identical_to_per_sample_kernel(B, nbits
         with torch.no_grad():
             bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0); bn.weight.normal_(); bn.bias.normal_()
     x = torch.randn(B, 384, device="cuda")
-    a = hash_tail(x, fc, bn, want=("logits", "codes", "packed"))
-    os.environ["WV_HASH_TAIL_SIMPLE"] = "1"
-    try:
-        b = hash_tail(x, fc, bn, want=("logits", "codes", "packed"))
-    finally:
-        del os.environ["WV_HASH_TAIL_SIMPLE"]
-    for k in ("logits", "codes", "packed"):
-        assert torch.equal(a[k], b[k]), k
+    want = ("logits", "codes", "packed")
+    out = {}
+    for kern in ("simple", "valu16", "mfma"):
+        monkeypatch.setenv("WV_HASH_TAIL", kern)
+        out[kern] = hash_tail(x, fc, bn, want=want)
+    for k in want:
+        assert torch.equal(out["valu16"][k], out["simple"][k]), k
+    assert (out["mfma"]["logits"] - out["simple"]["logits"]).abs().max().item() < 1e-5
+    far = out["simple"]["logits"].abs() > 1e-4
+    assert torch.equal(out["mfma"]["codes"][far], out["simple"]["codes"][far])
+    from wvhash.engine import hamming as H
+    assert torch.equal(out["mfma"]["packed"], H.pack_codes(out["mfma"]["codes"]))
+    monkeypatch.delenv("WV_HASH_TAIL")
+    auto = hash_tail(x, fc, bn, want=want)                       # what callers get: the matrix-core kernel from 32 samples on
+    for k in want:
+        assert torch.equal(auto[k], out["mfma"][k]), k
+    monkeypatch.setenv("WV_HASH_TAIL", "mfma")
+    for lo, hi in ((0, 1), (5, 37), (B - 33, B), (B // 2, B // 2 + 7)):
+        part = hash_tail(x[lo:hi].contiguous(), fc, bn, want=want)
+        for k in want:
+            assert torch.equal(part[k], out["mfma"][k][lo:hi]), (k, lo, hi)
 
 
 @pytest.mark.parametrize("ftype", ["cross_attention_advanced", "cross_attention_decoupled"])

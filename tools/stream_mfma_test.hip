@@ -9,7 +9,9 @@
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-template <int D>
+// MODE 0: as the fused head front runs it; 1: no refill loads (B stays in registers); 2: no LDS read (A stays in registers);
+// 3: neither -- a bare MFMA loop with this loop's bookkeeping
+template <int D, int MODE = 0>
 __global__ __launch_bounds__(256, 1) void k_stream(const f32x4 *__restrict__ Wp, float *__restrict__ out, int nchunks,
                                                    size_t wave_stride4)
 {
@@ -39,11 +41,13 @@ __global__ __launch_bounds__(256, 1) void k_stream(const f32x4 *__restrict__ Wp,
         for (int d = 0; d < D; ++d) {
             // refill the slot the previous step consumed (stream position: D - 1 chunks ahead of this step)
             const int slot = (d + D - 1) % D;
+            if (MODE == 0 || MODE == 2) {
 #pragma unroll
-            for (int b = 0; b < 3; ++b) ring[slot][b] = wq[(size_t)((d - 1) * 3 + b) * 64];
+                for (int b = 0; b < 3; ++b) ring[slot][b] = wq[(size_t)((d - 1) * 3 + b) * 64];
+            }
             const f32x4 av = av_n;
             ka = ka + 8 == 384 ? 0 : ka + 8;
-            av_n = *reinterpret_cast<const f32x4 *>(arow + ka);
+            if (MODE == 0 || MODE == 1) av_n = *reinterpret_cast<const f32x4 *>(arow + ka);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int b = 0; b < 3; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, ring[d][b].x, acc[b], 0, 0, 0);
@@ -65,24 +69,24 @@ __global__ __launch_bounds__(256, 1) void k_stream(const f32x4 *__restrict__ Wp,
     out[blockIdx.x * 256 + tid] = s;
 }
 
-template <int D>
+template <int D, int MODE = 0>
 static void run(const f32x4 *Wp, float *out, int nchunks, size_t ws4, int wgs)
 {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL(k_stream<D>, dim3(wgs), dim3(256), 0, 0, Wp, out, nchunks, ws4);
+    hipLaunchKernelGGL((k_stream<D, MODE>), dim3(wgs), dim3(256), 0, 0, Wp, out, nchunks, ws4);
     hipEventRecord(e0);
     const int reps = 5;
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_stream<D>, dim3(wgs), dim3(256), 0, 0, Wp, out, nchunks, ws4);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_stream<D, MODE>), dim3(wgs), dim3(256), 0, 0, Wp, out, nchunks, ws4);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     ms /= reps;
     const double fl = (double)wgs * 4 * nchunks * 12 * 4096.0;
-    printf("D=%d wgs=%d chunks/wave=%d: %.1f us  %.1f TFLOP/s  (weights per WG %.2f MB, L2->CU %.1f GB/s per CU)\n", D, wgs,
-           nchunks, ms * 1e3, fl / ms / 1e9, 4.0 * nchunks * 3072 / 1e6, 4.0 * nchunks * 3072 / (ms * 1e-3) / 1e9);
+    printf("mode %d D=%d wgs=%d chunks/wave=%d: %.1f us  %.1f TFLOP/s  (weights per WG %.2f MB, L2->CU %.1f GB/s per CU)\n", MODE, D, wgs,
+           nchunks, ms * 1e3, fl / ms / 1e9, 4.0 * nchunks * 3072 / 1e6, 4.0 * nchunks * 3072 / (ms * 1e-3) / 1e9 / 4);
 }
 
 int main()
@@ -101,6 +105,12 @@ int main()
         run<4>(Wp, out, nchunks, ws4, wgs);
         run<6>(Wp, out, nchunks, ws4, wgs);
         run<8>(Wp, out, nchunks, ws4, wgs);
+    }
+    for (int rep = 0; rep < 2; ++rep) {
+        run<4, 0>(Wp, out, nchunks, ws4, 256);
+        run<4, 1>(Wp, out, nchunks, ws4, 256);
+        run<4, 2>(Wp, out, nchunks, ws4, 256);
+        run<4, 3>(Wp, out, nchunks, ws4, 256);
     }
     if (hipDeviceSynchronize() != hipSuccess) return 1;
     return 0;
