@@ -124,11 +124,14 @@ def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, works
         # T = first bin b with (#rows of the whole database with distance <= b) >= k
         T = (cum_g[:, 1:] >= k).int().argmax(dim=1)
         need = torch.gather(cum, 1, (T + 1).unsqueeze(1).long()).max().reshape(1)   # local rows with distance <= T
-        _all_reduce(need, dist.ReduceOp.MAX, group)
         if send_hint is None:
+            _all_reduce(need, dist.ReduceOp.MAX, group)
             send = max(1, min(kin, int(need.item())))   # exact sizing: the one host read of the exchange
         else:
-            send = max(1, min(kin, int(send_hint)))     # no host read; the caller verifies need <= send_hint
+            # no host read and no MAX all-reduce: every rank sends `send_hint` entries, `need` stays THIS shard's own
+            # requirement and the caller verifies need <= send_hint on every rank (exchange_ok + one flag all-reduce
+            # whenever it synchronises anyway) -- one collective less in every steady-state step
+            send = max(1, min(kin, int(send_hint)))
     if trim and per <= 65536:
         # compact exchange: 16-bit LOCAL row numbers (2 bytes/entry) and, instead of a distance row, the shard's
         # cumulative histogram of each query (a sorted list is fully described by it): 2 bytes per entry + 4*(nbits+2)
