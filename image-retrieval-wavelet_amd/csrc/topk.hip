@@ -620,7 +620,8 @@ __global__ __launch_bounds__(256) void k_hit_prefix(const int32_t *__restrict__ 
 __global__ __launch_bounds__(256) void k_merge_cum(const uint16_t *__restrict__ idx_local,
                                                    const uint32_t *__restrict__ cum, int G, int Q, int kin,
                                                    int64_t shard_rows, int32_t *__restrict__ idx_out,
-                                                   uint8_t *__restrict__ dist_out, int k, int nbins)
+                                                   uint8_t *__restrict__ dist_out, int k, int nbins,
+                                                   int32_t *__restrict__ need_out)
 {
     extern __shared__ uint4 lds4[];
     int32_t *start = reinterpret_cast<int32_t *>(lds4);           // [G][nbins + 1]: first position with dist >= b
@@ -632,6 +633,44 @@ __global__ __launch_bounds__(256) void k_merge_cum(const uint16_t *__restrict__ 
         start[u] = (int32_t)min(cum[((int64_t)g * Q + qi) * (nbins + 1) + b], (uint32_t)kin);
     }
     __syncthreads();
+    if (need_out && wv == 1) {
+        // Was every shard's prefix long enough?  T = this query's global k-th distance (first bin b with
+        // sum_g cum[g][b + 1] >= k, from the UNclamped histograms); shard g had to send cum[g][T + 1] entries.  The
+        // largest such count over all (shard, query) pairs of this launch goes to need_out: exact iff it is <= kin.
+        int T = nbins - 1;
+        for (int c = 2; c >= 0; --c) {
+            const int b = 64 * c + lane;
+            uint32_t sb = 0;
+            if (b < nbins)
+                for (int g = 0; g < G; ++g) sb += cum[((int64_t)g * Q + qi) * (nbins + 1) + b + 1];
+            const uint64_t m = __ballot(b < nbins && sb >= (uint32_t)k);
+            if (m) T = 64 * c + __builtin_ctzll(m);
+        }
+        uint32_t nd = 0;
+        for (int g = lane; g < G; g += 64) nd = max(nd, cum[((int64_t)g * Q + qi) * (nbins + 1) + T + 1]);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) nd = max(nd, (uint32_t)__shfl_xor((int)nd, d, 64));
+        if (lane == 0) atomicMax(need_out, (int32_t)min(nd, 0x7fffffffu));
+    }
+    if (need_out && wv == 1) {
+        // Was every shard's prefix long enough?  T = this query's global k-th distance (first bin b with
+        // sum_g cum[g][b + 1] >= k, from the UNclamped histograms); shard g had to send cum[g][T + 1] entries.  The
+        // largest such count over all (shard, query) pairs of this launch goes to need_out: exact iff it is <= kin.
+        int T = nbins - 1;
+        for (int c = 2; c >= 0; --c) {
+            const int b = 64 * c + lane;
+            uint32_t sb = 0;
+            if (b < nbins)
+                for (int g = 0; g < G; ++g) sb += cum[((int64_t)g * Q + qi) * (nbins + 1) + b + 1];
+            const uint64_t m = __ballot(b < nbins && sb >= (uint32_t)k);
+            if (m) T = 64 * c + __builtin_ctzll(m);
+        }
+        uint32_t nd = 0;
+        for (int g = lane; g < G; g += 64) nd = max(nd, cum[((int64_t)g * Q + qi) * (nbins + 1) + T + 1]);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) nd = max(nd, (uint32_t)__shfl_xor((int)nd, d, 64));
+        if (lane == 0) atomicMax(need_out, (int32_t)min(nd, 0x7fffffffu));
+    }
     if (wv == 0) {   // totals per bin and their exclusive scan (up to 3 bins per lane)
         uint32_t t[3] = {0, 0, 0};
         const int b0 = 3 * lane;
@@ -848,8 +887,17 @@ extern "C" int wv_topk_merge(const int32_t *idx_in, const uint8_t *dist_in, int 
     return WV_OK;
 }
 
+extern "C" int wv_topk_merge_cum_need(const uint16_t *idx_local, const uint32_t *cum, int G, int Q, int kin, int64_t shard_rows,
+                                      int32_t *idx_out, uint8_t *dist_out, int k, int nbits, int32_t *need_out, void *stream);
+
 extern "C" int wv_topk_merge_cum(const uint16_t *idx_local, const uint32_t *cum, int G, int Q, int kin,
                                  int64_t shard_rows, int32_t *idx_out, uint8_t *dist_out, int k, int nbits, void *stream)
+{
+    return wv_topk_merge_cum_need(idx_local, cum, G, Q, kin, shard_rows, idx_out, dist_out, k, nbits, nullptr, stream);
+}
+
+extern "C" int wv_topk_merge_cum_need(const uint16_t *idx_local, const uint32_t *cum, int G, int Q, int kin, int64_t shard_rows,
+                                      int32_t *idx_out, uint8_t *dist_out, int k, int nbits, int32_t *need_out, void *stream)
 {
     WV_REQUIRE(idx_local && cum && idx_out, "topk_merge_cum: null buffer");
     WV_REQUIRE(G >= 1 && Q >= 0 && kin >= 1 && k >= 1, "topk_merge_cum: bad shape G=%d Q=%d kin=%d k=%d", G, Q, kin, k);
@@ -862,7 +910,7 @@ extern "C" int wv_topk_merge_cum(const uint16_t *idx_local, const uint32_t *cum,
     const size_t lds = ((size_t)G * (nbins + 1) + (size_t)G * nbins + nbins + 1 + 4) * 4;
     WV_REQUIRE(lds <= 60 * 1024, "topk_merge_cum: too many shards (G=%d)", G);
     hipLaunchKernelGGL(k_merge_cum, dim3(Q), dim3(256), lds, (hipStream_t)stream, idx_local, cum, G, Q, kin, shard_rows,
-                       idx_out, dist_out, k, nbins);
+                       idx_out, dist_out, k, nbins, need_out);
     WV_CHECK_LAUNCH("k_merge_cum");
     return WV_OK;
 }
@@ -1021,6 +1069,17 @@ extern "C" int wv_hamming_hist(const uint64_t *q, const uint64_t *db, const void
     WV_REQUIRE(nbits >= 1 && nbits <= 128, "hamming_hist: nbits=%d (supported: 1..128)", nbits);
     if (Q == 0) return WV_OK;
     return shard_call("hamming_hist", q, db, prepared, nullptr, cum, Q, N, nbits, 0, workspace, workspace_bytes, stream);
+}
+
+extern "C" int wv_hamming_shard_prefix(const uint64_t *q, const uint64_t *db, const void *prepared, uint16_t *rows, uint32_t *cum,
+                                       int Q, int64_t N, int nbits, int k, void *workspace, size_t workspace_bytes, void *stream)
+{
+    WV_REQUIRE(q && rows && cum && (db || prepared), "hamming_shard_prefix: null buffer");
+    WV_REQUIRE(Q >= 0 && N >= 1, "hamming_shard_prefix: bad shape Q=%d N=%lld", Q, (long long)N);
+    WV_REQUIRE(nbits >= 1 && nbits <= 128, "hamming_shard_prefix: nbits=%d (supported: 1..128)", nbits);
+    WV_REQUIRE(k >= 1 && k <= N, "hamming_shard_prefix: k=%d must be in [1, N=%lld]", k, (long long)N);
+    if (Q == 0) return WV_OK;
+    return shard_call("hamming_shard_prefix", q, db, prepared, rows, cum, Q, N, nbits, k, workspace, workspace_bytes, stream);
 }
 
 extern "C" int wv_hamming_topk_rows16(const uint64_t *q, const uint64_t *db, const void *prepared, uint16_t *rows, int Q,

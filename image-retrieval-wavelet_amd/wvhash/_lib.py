@@ -77,11 +77,13 @@ SIGNATURES = {
     "wv_hamming_map_at_k": (_i, [_vp, _vp, _vp, _vp, _i, ctypes.c_int64, _i, _i, _vp, _vp, _vp]),
     "wv_hamming_hist": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _sz, _vp]),
     "wv_hamming_topk_rows16": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _sz, _vp]),
+    "wv_hamming_shard_prefix": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _sz, _vp]),
     "wv_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
     "wv_rank_from_dist": (_i, [_vp, _i64, _i, _i64, _i, _vp, _vp, _i, _vp]),
     "wv_map_at_k": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "wv_map_at_k_ld": (_i, [_vp, _i64, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "wv_topk_merge_cum": (_i, [_vp, _vp, _i, _i, _i, _i64, _vp, _vp, _i, _i, _vp]),
+    "wv_topk_merge_cum_need": (_i, [_vp, _vp, _i, _i, _i, _i64, _vp, _vp, _i, _i, _vp, _vp]),
     "wv_hit_prefix": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "wv_knn_float_workspace_bytes": (_sz, [_i, _i64, _i, _i]),
     "wv_knn_float": (_i, [_vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),

@@ -229,6 +229,25 @@ def hamming_topk_rows16(q_packed, db, nbits, k, workspace=None):
     return rows
 
 
+def hamming_shard_prefix(q_packed, db, nbits, k, workspace=None):
+    """hamming_topk_rows16 and hamming_hist in one pass -> (rows int16 [Q, k], cum int32 [Q, nbits + 2])."""
+    lib = _lib.require_gpu()
+    Q, words = q_packed.shape
+    prepared, N = _shard_db_args(db, words, nbits, "hamming_shard_prefix")
+    dev = q_packed.device
+    rows = torch.empty((Q, k), dtype=torch.int16, device=dev)
+    cum = torch.empty((Q, nbits + 2), dtype=torch.int32, device=dev)
+    ws = None
+    if not prepared:
+        ws = (workspace or TopkWorkspace()).get(lib.wv_hamming_topk_workspace_bytes(Q, N, words, k), dev)
+    with torch.cuda.device(dev):
+        rc = lib.wv_hamming_shard_prefix(_lib.ptr(q_packed), None if prepared else _lib.ptr(db),
+                                         _lib.ptr(db.blob) if prepared else None, _lib.ptr(rows), _lib.ptr(cum), Q, N, nbits, k,
+                                         _lib.ptr(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0), _lib.stream_ptr())
+        _lib.check(rc, "wv_hamming_shard_prefix")
+    return rows, cum
+
+
 def topk_merge(idx_in, dist_in, k, nbits):
     """[G,Q,kin] per-shard lists (contiguous row shards in rank order) -> global [Q,k]."""
     lib = _lib.require_gpu()
@@ -243,9 +262,11 @@ def topk_merge(idx_in, dist_in, k, nbits):
     return idx, dist
 
 
-def topk_merge_cum(idx_local, cum, shard_rows, k, nbits):
+def topk_merge_cum(idx_local, cum, shard_rows, k, nbits, need_out=None):
     """Compact merge: idx_local int16 storage of uint16 LOCAL row numbers [G,Q,kin], cum int32 [G,Q,nbits+2]
-    (per-shard cumulative distance histograms) -> global (idx int32 [Q,k], dist uint8 [Q,k])."""
+    (per-shard cumulative distance histograms) -> global (idx int32 [Q,k], dist uint8 [Q,k]).
+    need_out: int32 [1] device tensor (zeroed by the caller) that receives the longest prefix any shard had to contribute
+    for any of these queries -- the lists are exact iff it is <= kin."""
     lib = _lib.require_gpu()
     G, Q, kin = idx_local.shape
     if idx_local.dtype != torch.int16 or cum.dtype != torch.int32 or tuple(cum.shape) != (G, Q, nbits + 2):
@@ -254,9 +275,10 @@ def topk_merge_cum(idx_local, cum, shard_rows, k, nbits):
     idx = torch.empty((Q, k), dtype=torch.int32, device=idx_local.device)
     dist = torch.empty((Q, k), dtype=torch.uint8, device=idx_local.device)
     with torch.cuda.device(idx_local.device):
-        rc = lib.wv_topk_merge_cum(_lib.ptr(idx_local), _lib.ptr(cum), G, Q, kin, shard_rows, _lib.ptr(idx),
-                                   _lib.ptr(dist), k, nbits, _lib.stream_ptr())
-        _lib.check(rc, "wv_topk_merge_cum")
+        rc = lib.wv_topk_merge_cum_need(_lib.ptr(idx_local), _lib.ptr(cum), G, Q, kin, shard_rows, _lib.ptr(idx),
+                                        _lib.ptr(dist), k, nbits, _lib.ptr(need_out) if need_out is not None else None,
+                                        _lib.stream_ptr())
+        _lib.check(rc, "wv_topk_merge_cum_need")
     return idx, dist
 
 

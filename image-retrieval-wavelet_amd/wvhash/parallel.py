@@ -77,8 +77,9 @@ def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, works
 
     send_hint (with trim): prefix length to exchange WITHOUT the host read -- for a steady stream of query batches
     (serving, bench.py) whose needed length is known from earlier batches.  The call then never synchronises with the
-    host; the result is exact iff the returned `need` (device int32 [1], return_need=True) is <= send_hint, which
-    the caller checks whenever it next synchronises anyway (`exchange_ok`).
+    host and runs no all-reduce (one ranking pass per shard, two all_to_alls, the merge); the result is exact iff the
+    returned `need` (device int32 [1], return_need=True: the longest prefix any shard owed one of THIS rank's queries) is
+    <= send_hint on every rank, which the caller checks whenever it next synchronises anyway (`exchange_ok`).
 
     want_dist=False: the caller only needs the ranked lists (mAP does: calculate_maphashing, accuracy_calculator.py:183-231,
     never looks at the distances once the order is known).  With one rank the distance row is then not written at all
@@ -105,6 +106,28 @@ def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, works
     # each query's global k-th distance BEFORE any list is built; the shard then ranks only the prefix that can matter
     # (about k / world + ties entries instead of min(k, shard rows)) and writes it straight in the 16-bit wire format.
     two_step = trim and 0 < n_local <= H.SHARD_ROWS_MAX and per <= H.SHARD_ROWS_MAX
+    if trim and send_hint is not None and per <= H.SHARD_ROWS_MAX:
+        # Hinted steady state: the prefix length is known, so nothing has to be learned before the lists are built.
+        # ONE ranking pass per shard (the `send` nearest rows as 16-bit local numbers + the complete histograms), the two
+        # all_to_alls, the merge -- no all-reduce at all (3 collectives per step instead of 5).  Whether `send` was enough
+        # is decided where the lists arrive: the merge kernel has every shard's histograms of its queries, derives each
+        # query's global k-th distance T and reports the longest prefix any shard owed (`need`, device int32 [1]).
+        send = max(1, min(kin, int(send_hint)))
+        if n_local > 0:
+            w = min(send, n_local)
+            loc_s, cum = H.hamming_shard_prefix(q_all, db_shard, nbits, w, workspace=workspace)
+            if w < send:
+                loc_s = torch.nn.functional.pad(loc_s, (0, send - w))
+        else:                                           # empty shard: contributes nothing
+            loc_s = torch.zeros((world * Ql, send), dtype=torch.int16, device=dev)
+            cum = torch.zeros((world * Ql, nbits + 2), dtype=torch.int32, device=dev)
+        loc_r = torch.empty_like(loc_s)
+        _all_to_all(loc_r.view(torch.uint8), loc_s.contiguous().view(torch.uint8), group)
+        cum_r = torch.empty_like(cum)
+        _all_to_all(cum_r, cum.contiguous(), group)
+        need = torch.zeros(1, dtype=torch.int32, device=dev)
+        out = H.topk_merge_cum(loc_r.view(world, Ql, send), cum_r.view(world, Ql, nbits + 2), per, k, nbits, need_out=need)
+        return (out[0], out[1], need) if return_need else out
     if k_local > 0 and not two_step:
         if trim:
             # the compact exchange below ships histograms, not distance rows: do not even write them

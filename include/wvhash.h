@@ -206,6 +206,12 @@ int wv_hamming_hist(const uint64_t *q, const uint64_t *db, const void *prepared,
                     void *workspace, size_t workspace_bytes, void *stream);
 int wv_hamming_topk_rows16(const uint64_t *q, const uint64_t *db, const void *prepared, uint16_t *rows, int Q, int64_t N,
                            int nbits, int k, void *workspace, size_t workspace_bytes, void *stream);
+/* Both in one pass, for a steady stream of query batches whose prefix length is known from earlier batches (wvhash/parallel.py
+ * with send_hint): the shard's k nearest rows per query as 16-bit local row numbers AND its complete cumulative histograms.
+ * No all-reduce is needed before the lists can be built; whether k was enough is checked by the receiver of the lists
+ * (wv_topk_merge_cum_need). */
+int wv_hamming_shard_prefix(const uint64_t *q, const uint64_t *db, const void *prepared, uint16_t *rows, uint32_t *cum, int Q,
+                            int64_t N, int nbits, int k, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Merge of G per-shard top-k lists (gathered with one all-gather) into the global top-k.
  * Replaces the host-side shard merge inside faiss.index_cpu_to_all_gpus(shards=True)
@@ -224,6 +230,11 @@ int wv_topk_merge(const int32_t *idx_in, const uint8_t *dist_in, int G, int Q, i
  * exchanged bytes than int32 indices + uint8 distances. */
 int wv_topk_merge_cum(const uint16_t *idx_local, const uint32_t *cum, int G, int Q, int kin, int64_t shard_rows,
                       int32_t *idx_out, uint8_t *dist_out, int k, int nbits, void *stream);
+/* The same merge; additionally need_out[0] = max(need_out[0], the longest prefix any shard had to contribute for a query of
+ * this launch) -- from the unclamped histograms: the merged lists are exact iff that value is <= kin.  The caller zeroes
+ * need_out beforehand and looks at it whenever it synchronises anyway. */
+int wv_topk_merge_cum_need(const uint16_t *idx_local, const uint32_t *cum, int G, int Q, int kin, int64_t shard_rows,
+                           int32_t *idx_out, uint8_t *dist_out, int k, int nbits, int32_t *need_out, void *stream);
 
 /* Ranking from a stored distance matrix row (same order as wv_hamming_topk). */
 int wv_rank_from_dist(const uint8_t *dist_matrix, int64_t ld_dist, int Q, int64_t N, int nbits,

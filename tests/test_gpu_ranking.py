@@ -532,6 +532,28 @@ def test_two_step_sharded_search_on_one_gpu(Q, N, nbits, k, G, prepared):
     mi, md = H.topk_merge_cum(torch.stack(lists), cum, per, k, nbits)
     assert torch.equal(mi, full_idx) and torch.equal(md, full_d)
     assert send < min(k, per) or G == 1 or k >= N            # the trimmed prefix really is shorter than the full list
+    # the hinted one-pass form: list prefix and complete histograms from ONE kernel per shard, the check of the prefix
+    # length done by the merge (need_out = the longest prefix any shard owed) -- no histogram sum beforehand
+    for hint, exact in ((send, True), (max(1, send - 1), send == 1)):
+        hint = min(hint, min(k, per))
+        l2, c2 = [], []
+        for lo, hi, db in shards:
+            loc = torch.zeros((Q, hint), dtype=torch.int16, device="cuda")
+            c = torch.zeros((Q, nbits + 2), dtype=torch.int32, device="cuda")
+            w = min(hint, hi - lo)
+            if w > 0:
+                rows, c = H.hamming_shard_prefix(qp, db, nbits, w)
+                loc[:, :w] = rows
+                assert torch.equal(rows, H.hamming_topk_rows16(qp, db, nbits, w))
+            l2.append(loc)
+            c2.append(c)
+        assert torch.equal(torch.stack(c2), cum)
+        owed = torch.zeros(1, dtype=torch.int32, device="cuda")
+        mi2, md2 = H.topk_merge_cum(torch.stack(l2), cum, per, k, nbits, need_out=owed)
+        assert int(owed.item()) == need
+        assert (int(owed.item()) <= hint) == exact
+        if exact:
+            assert torch.equal(mi2, full_idx) and torch.equal(md2, full_d)
 
 
 @pytest.mark.parametrize("Q,N,k,Lc", [(64, 25000, 5000, 38), (37, 3000, 3000, 20), (9, 130, 7, 64)])

@@ -64,9 +64,17 @@ def _fake_merge(idx_in, dist_in, k, nbits):
     return torch.gather(ids, 1, order), torch.gather(key, 1, order).to(torch.uint8)
 
 
-def _fake_merge_cum(idx_local, cum, shard_rows, k, nbits):
+def _fake_shard_prefix(q_packed, db, nbits, k, workspace=None):
+    return _fake_rows16(q_packed, db, nbits, k), _fake_hist(q_packed, db, nbits)
+
+
+def _fake_merge_cum(idx_local, cum, shard_rows, k, nbits, need_out=None):
     """Expand the compact form (16-bit local rows + per-shard cumulative histograms) and merge as above."""
     G, Q, kin = idx_local.shape
+    if need_out is not None:       # longest prefix any shard owed: cum[g, q, T_q + 1], T_q = global k-th distance of query q
+        T = (cum.sum(0)[:, 1:] >= k).int().argmax(dim=1)
+        owed = torch.gather(cum, 2, (T + 1).view(1, Q, 1).expand(G, Q, 1).long()).max()
+        need_out.copy_(torch.maximum(need_out, owed.reshape(1).int()))
     ids = (idx_local.long() & 0xffff) + (torch.arange(G) * shard_rows).view(G, 1, 1)
     pos = torch.arange(kin).view(1, 1, kin)
     # distance of position p of a sorted list = number of boundaries cum[1:] that are <= p
@@ -83,7 +91,7 @@ def _worker(rank, world, port, cases, nbits, ql, out_dir):
     from wvhash import parallel, synth
     from wvhash.engine import hamming as H
     H.hamming_topk, H.topk_merge, H.topk_merge_cum = _fake_topk, _fake_merge, _fake_merge_cum   # CPU stand-ins for the kernels
-    H.hamming_hist, H.hamming_topk_rows16 = _fake_hist, _fake_rows16
+    H.hamming_hist, H.hamming_topk_rows16, H.hamming_shard_prefix = _fake_hist, _fake_rows16, _fake_shard_prefix
     out = {}
     for n_db, k in cases:
         q_all, r = synth.random_codes(world * ql, n_db, nbits, seed=3)

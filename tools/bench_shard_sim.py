@@ -7,8 +7,9 @@ import torch
 from wvhash import synth
 from wvhash.engine import hamming as H
 
-def timeit(fn, reps=10):
-    fn(); torch.cuda.synchronize()
+def timeit(fn, reps=20):
+    for _ in range(30): fn()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps): fn()
@@ -25,6 +26,7 @@ for world in (1, 2, 4, 8):
     send = min(kl, int(K / world * 1.6) + 64)
     t_hist = timeit(lambda: H.hamming_hist(qp, prep, 64))
     t_rows = timeit(lambda: H.hamming_topk_rows16(qp, prep, 64, send))
+    t_one = timeit(lambda: H.hamming_shard_prefix(qp, prep, 64, send))       # hinted steady state: lists + histograms, one pass
     # what a rank receives for ITS QL queries: per shard the list prefix (16-bit local rows) + the cumulative histogram
     _, _, cum = H.hamming_topk(qp[:QL], prep, 64, kl, want_dist=False, want_cum=True)
     loc = torch.randint(0, per, (world, QL, send), dtype=torch.int32, device="cuda").to(torch.int16)
@@ -33,5 +35,6 @@ for world in (1, 2, 4, 8):
     mb = world * QL * (send * 2 + 66 * 4) / 1e6
     print(f"world={world}: one-step local rank of {world*QL} queries vs {per} rows (k'={kl}): {t_local*1e3:.0f} us | "
           f"two-step: histograms {t_hist*1e3:.0f} us + {send}-entry 16-bit lists {t_rows*1e3:.0f} us | "
+          f"hinted one pass (lists + histograms): {t_one*1e3:.0f} us | "
           f"compact merge {world} x {send}: {t_merge*1e3:.0f} us | sent per rank ~{mb:.0f} MB "
           f"(int32+u8 lists: {world * QL * send * 5 / 1e6:.0f} MB)", flush=True)
