@@ -101,6 +101,9 @@ class Pipeline:
         # one GPU: mAP needs no list -- ranking and AP run as one kernel (wv_hamming_map_at_k); with more ranks the
         # lists are what the shards exchange, so the two kernels stay
         self.lab_prepared = Hm.PreparedLabels(self.dblab) if world == 1 else None
+        # more ranks: once the prefix length is known (first, exactly-sized list step) the shards send relevance strings
+        # instead of lists (sharded_hamming_map_at_k)
+        self.lab_shard = Hm.PreparedLabels(self.dblab[self.lo:self.hi].contiguous()) if world > 1 and self.hi > self.lo else None
         self.ws = Hm.TopkWorkspace()
         self.Hm = Hm
         self.db_codes_cpu = db_codes
@@ -167,8 +170,16 @@ class Pipeline:
         self._mark("tail1")
         fused_ap = (self.Hm.hamming_map_at_k(packed, self.db_shard, self.lab_prepared, self.qlab, NBITS, TOPK)
                     if self.lab_prepared is not None else None)
+        sharded_ap = None
+        if fused_ap is None and self.world > 1 and self.send_hint is not None:   # the same decision on every rank
+            from wvhash.parallel import sharded_hamming_map_at_k
+            sharded_ap = sharded_hamming_map_at_k(packed, self.qlab, self.db_shard, self.lab_shard, NBITS, TOPK, N_DB, self.send_hint)
         if fused_ap is not None:
             idx, ap = None, fused_ap[0]
+            self._mark("rankmap1")
+        elif sharded_ap is not None:
+            idx, ap = None, sharded_ap[0]
+            self.needs.append(sharded_ap[2])
             self._mark("rankmap1")
         else:
             idx, _ = self.stage_rank(packed)
@@ -516,7 +527,9 @@ def main():
                          f"{dist.get_backend()} (REHEARSAL: {world} ranks share {torch.cuda.device_count()} GPU(s), "
                          "collectives staged through host memory)") if world > 1 else "none"),
             "exchange": exchange,
-            "parallelism": f"db row-sharded x{world}, all_gather(codes)+all_to_all(top-k lists)" if world > 1 else "single GPU",
+            "parallelism": (f"db row-sharded x{world}: all_gather(codes + label words), one ranking pass per shard, "
+                            "all_to_all(relevance strings of the list prefixes + histograms), merge + AP on the receiving rank "
+                            "(first step: lists, to size the prefix)") if world > 1 else "single GPU",
         },
     }
     if rank == 0 and world == 1:

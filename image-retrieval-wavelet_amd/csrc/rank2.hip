@@ -30,6 +30,7 @@
 // Covers databases (shards) of at most 32,768 rows -- C <= 128 items per thread, their distances cached in registers as
 // bytes; 16-bit item numbers and counters -- and k small enough for the LDS list; everything else stays on topk.hip's kernel.
 #include "common.hpp"
+#include "ap_walk.hpp"
 
 namespace wv {
 
@@ -95,8 +96,8 @@ struct Rank2Ap {
     const uint64_t *qlab;    // [Q] label word of every query
     float *ap;               // [Q]
     int32_t *nrel;           // [Q] relevant entries among the k (or NULL)
+    uint64_t *relbits;       // [Q][ceil(k / 64)] instead of ap: the relevance string of the list (sharded mAP)
 };
-constexpr int kApRounds = 32;                // list positions per thread the AP walk keeps as bits: k <= 32 * TPQ
 
 // words of the relevance bitmap: one bit per database row
 __host__ __device__ inline int rank2_bitmap_words(int64_t N) { return (int)((N + 31) / 32); }
@@ -266,15 +267,17 @@ __device__ __forceinline__ void rank2_relevance_bitmap(const uint32_t *__restric
 
 // AP of the list in LDS (k_map_at_k's arithmetic and order: position p = round * TPQ + t, the j-th hit adds the fp32
 // quotient j / (p + 1) to a double, waves summed in index order).  scratch: free LDS, (32 * NW + 2 * NW + 2) dwords.
+// relbits_out (or NULL): the relevance string itself, bit p of the uint64 array = relevance of list position p -- what a
+// shard contributes to the sharded mAP (wv_hamming_shard_relbits); no AP is computed then.
 template <int TPQ>
 __device__ __forceinline__ void rank2_ap(const uint16_t *stage, const uint32_t *bitmap, uint32_t *scratch, int k, int t,
-                                         float *__restrict__ ap_out, int32_t *__restrict__ nrel_out)
+                                         float *__restrict__ ap_out, int32_t *__restrict__ nrel_out,
+                                         uint64_t *__restrict__ relbits_out)
 {
     constexpr int NW = TPQ / 64;
     const int lane = t & 63, wv = t >> 6;
     const int R = (k + TPQ - 1) / TPQ;                           // <= kApRounds (host check)
     uint32_t *cnt = scratch;                                     // [R][NW] hits of a wave in a round
-    double *wsum = reinterpret_cast<double *>(scratch + kApRounds * NW + (kApRounds * NW & 1));
     // Eight rounds at a time, every LDS read of a batch issued before the first is used: with other workgroups' atomics
     // queued at the LDS unit a read takes ~1k cycles, and a chain of dependent ones (list entry -> bitmap word, round
     // after round) would pay that 2 R times.
@@ -292,48 +295,14 @@ __device__ __forceinline__ void rank2_ap(const uint16_t *stage, const uint32_t *
             const bool rel = r < R && r * TPQ + t < k && ((wd[u] >> (it[u] & 31)) & 1u);
             relbits |= (rel ? 1u : 0u) << (r & 31);
             const uint64_t m = __ballot(rel);
-            if (lane == 0 && r < R) cnt[r * NW + wv] = (uint32_t)__popcll(m);
-        }
-    }
-    group_sync<TPQ>();
-    uint32_t running = 0;
-    double acc = 0.0;
-    for (int r0 = 0; r0 < R; r0 += CH) {
-        uint32_t c[CH][NW];
-#pragma unroll
-        for (int u = 0; u < CH; ++u)
-#pragma unroll
-            for (int w2 = 0; w2 < NW; ++w2) c[u][w2] = cnt[min(r0 + u, R - 1) * NW + w2];
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            const int r = r0 + u;
-            if (r < R) {                                          // uniform
-                uint32_t before = running, tot = 0;
-#pragma unroll
-                for (int w2 = 0; w2 < NW; ++w2) {
-                    before += w2 < wv ? c[u][w2] : 0u;
-                    tot += c[u][w2];
-                }
-                const bool rel = (relbits >> r) & 1u;
-                const uint64_t m = __ballot(rel);
-                if (rel) {
-                    const uint32_t j = before + (uint32_t)mbcnt(m) + 1;
-                    acc += (double)((float)j / (float)(r * TPQ + t + 1));
-                }
-                running += tot;
+            if (lane == 0 && r < R) {
+                cnt[r * NW + wv] = (uint32_t)__popcll(m);
+                if (relbits_out && (r * NW + wv) * 64 < k) relbits_out[r * NW + wv] = m;
             }
         }
     }
-    acc = wave_sum_f64(acc);
-    if (lane == 0) wsum[wv] = acc;
-    group_sync<TPQ>();
-    if (t == 0) {
-        double s = wsum[0];
-#pragma unroll
-        for (int w2 = 1; w2 < NW; ++w2) s += wsum[w2];
-        *ap_out = running ? (float)(s / (double)running) : 0.0f;
-        if (nrel_out) *nrel_out = (int32_t)running;
-    }
+    if (relbits_out) return;                                     // a shard of the sharded mAP: the string is all it sends
+    ap_finish<TPQ>(relbits, scratch, R, t, ap_out, nrel_out, [] { group_sync<TPQ>(); });
 }
 
 // Ranks ONE query from its cached distances.  Ends with a group barrier: the LDS region may be reused at once.
@@ -344,7 +313,8 @@ __device__ __forceinline__ void rank2_one_query(const uint32_t (&dc)[NC], uint32
                                                 uint16_t *__restrict__ rows16_out, uint8_t *__restrict__ dist_out,
                                                 uint32_t *__restrict__ cum_out, uint8_t *lds_raw, int t,
                                                 const uint32_t *__restrict__ cls = nullptr, uint64_t qlabel = 0,
-                                                float *__restrict__ ap_out = nullptr, int32_t *__restrict__ nrel_out = nullptr)
+                                                float *__restrict__ ap_out = nullptr, int32_t *__restrict__ nrel_out = nullptr,
+                                                uint64_t *__restrict__ relbits_out = nullptr)
 {
     // k == 0: histogram only (cum_out), no list.  rows16_out: the list as 16-bit LOCAL row numbers instead of idx_out.
     constexpr int ROWB = TPQ * 2;                                // bytes per table row
@@ -569,7 +539,7 @@ __device__ __forceinline__ void rank2_one_query(const uint32_t (&dc)[NC], uint32
         }
     }
     R2_STAMP(5);
-    if constexpr (AP) rank2_ap<TPQ>(L.stage, bitmap, L.table, k, t, ap_out, nrel_out);   // the count table is free by now
+    if constexpr (AP) rank2_ap<TPQ>(L.stage, bitmap, L.table, k, t, ap_out, nrel_out, relbits_out);   // the count table is free by now
     R2_STAMP(7);
     group_sync<TPQ>();                                            // the next query of the group reuses this LDS
 }
@@ -668,7 +638,8 @@ __global__ __launch_bounds__(256, rank2_min_waves(NC, QB)) void k_rank_window(co
                 rank2_one_query<TPQ, NC, true>(dc[qq], dmin[qq], N, C, nbins, k, idx_offset, idx ? idx + (int64_t)qi * k : nullptr,
                                                rows16 ? rows16 + (int64_t)qi * k : nullptr, dist ? dist + (int64_t)qi * k : nullptr,
                                                cum ? cum + (int64_t)qi * (nbins + 1) : nullptr, lds, t, apx.cls, ql,
-                                               apx.ap + qi, apx.nrel ? apx.nrel + qi : nullptr);
+                                               apx.ap ? apx.ap + qi : nullptr, apx.nrel ? apx.nrel + qi : nullptr,
+                                               apx.relbits ? apx.relbits + (int64_t)qi * ((k + 63) / 64) : nullptr);
             } else {
                 rank2_one_query<TPQ, NC>(dc[qq], dmin[qq], N, C, nbins, k, idx_offset, idx ? idx + (int64_t)qi * k : nullptr,
                                          rows16 ? rows16 + (int64_t)qi * k : nullptr, dist ? dist + (int64_t)qi * k : nullptr,
@@ -718,8 +689,8 @@ static int launch_rank2_qb(const uint64_t *q, const void *img, int32_t *idx, uin
                            int C, int nbins, int k, int64_t idx_offset, uint32_t *cum, const Rank2Ap &apx, hipStream_t st)
 {
     constexpr int GPW = 256 / TPQ;
-    const size_t per_g = rank2_lds_bytes_per_query<TPQ>(k, apx.ap ? rank2_bitmap_words(N) : 0), lds = per_g * GPW;
-    auto kern = apx.ap ? k_rank_window<WORDS, TPQ, NC, QB, true> : k_rank_window<WORDS, TPQ, NC, QB, false>;
+    const size_t per_g = rank2_lds_bytes_per_query<TPQ>(k, (apx.ap || apx.relbits) ? rank2_bitmap_words(N) : 0), lds = per_g * GPW;
+    auto kern = (apx.ap || apx.relbits) ? k_rank_window<WORDS, TPQ, NC, QB, true> : k_rank_window<WORDS, TPQ, NC, QB, false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) WV_FAIL(WV_EHIP, "rank_window: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
@@ -764,11 +735,11 @@ static int launch_rank2_t(const uint64_t *q, const void *img, int32_t *idx, uint
 // idx (int32 global indices) or rows16 (16-bit local row numbers) receives the list; k == 0: histogram only
 int rank2_launch(const uint64_t *q, const void *img, int32_t *idx, uint16_t *rows16, uint8_t *dist, int Q, int64_t N, int nbits,
                  int k, int64_t idx_offset, uint32_t *cum, int tpq, hipStream_t st, const void *lab_img, const uint64_t *qlab,
-                 float *ap, int32_t *nrel)
+                 float *ap, int32_t *nrel, uint64_t *relbits)
 {
     const int nbins = nbits + 1, words = (nbits + 63) / 64;
-    Rank2Ap apx{reinterpret_cast<const uint32_t *>(lab_img), qlab, ap, nrel};
-    if (ap) {
+    Rank2Ap apx{reinterpret_cast<const uint32_t *>(lab_img), qlab, ap, nrel, relbits};
+    if (ap || relbits) {
         if (!lab_img || !qlab || k < 1 || k > kApRounds * tpq) return 1;                     // the AP walk keeps <= 32 positions per thread
         const size_t per_g = tpq == 64 ? 4 * rank2_lds_bytes_per_query<64>(k, rank2_bitmap_words(N))
                                        : rank2_lds_bytes_per_query<256>(k, rank2_bitmap_words(N));

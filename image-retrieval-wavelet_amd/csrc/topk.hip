@@ -15,6 +15,7 @@
 // per-thread contiguous ranges are read with fully coalesced loads.  The distance row is not
 // scattered at all: it is regenerated from the bin boundaries (sorted => run-length).
 #include "common.hpp"
+#include "ap_walk.hpp"
 #include <type_traits>
 
 namespace wv {
@@ -30,7 +31,7 @@ int rank2_labels_prepare(const uint64_t *dblab, void *cls, int64_t N, hipStream_
 // lab_img (the class-major label bit matrix) / qlab / ap / nrel: average precision of the list (wv_hamming_map_at_k); all NULL otherwise
 int rank2_launch(const uint64_t *q, const void *img, int32_t *idx, uint16_t *rows16, uint8_t *dist, int Q, int64_t N, int nbits,
                  int k, int64_t idx_offset, uint32_t *cum, int tpq, hipStream_t st, const void *lab_img = nullptr,
-                 const uint64_t *qlab = nullptr, float *ap = nullptr, int32_t *nrel = nullptr);
+                 const uint64_t *qlab = nullptr, float *ap = nullptr, int32_t *nrel = nullptr, uint64_t *relbits = nullptr);
 // the one-wave-per-query image exists for databases (shards) of at most this many rows
 constexpr int64_t kImg64MaxRows = 64 * 64;
 // images of the windowed kernel exist for databases it can take at all (16-bit item numbers, <= 128 items per thread)
@@ -887,6 +888,94 @@ extern "C" int wv_topk_merge(const int32_t *idx_in, const uint8_t *dist_in, int 
     return WV_OK;
 }
 
+namespace wv {
+// Sharded mAP, receiving side: per query the G shards' relevance strings (bit p = is the shard's p-th nearest row relevant)
+// and cumulative histograms -> average precision.  The global list orders entries by (distance, shard, position), so the
+// merged relevance string is the concatenation, bin by bin and shard by shard, of runs of the shards' strings; it is
+// assembled in LDS (k bits) with shifted 32-bit copies and walked exactly as k_map_at_k walks a list (ap_walk.hpp).
+// need_out: as in k_merge_cum.
+__global__ __launch_bounds__(256) void k_merge_relbits_ap(const uint32_t *__restrict__ relbits, const uint32_t *__restrict__ cum,
+                                                          int G, int Q, int kin, int w32, int k, int nbins,
+                                                          float *__restrict__ ap, int32_t *__restrict__ nrel,
+                                                          int32_t *__restrict__ need_out)
+{
+    extern __shared__ uint4 lds4[];
+    int32_t *start = reinterpret_cast<int32_t *>(lds4);           // [G][nbins + 1]: first position with dist >= b
+    uint32_t *base = reinterpret_cast<uint32_t *>(start + G * (nbins + 1));   // [nbins + 1]
+    uint32_t *M = base + nbins + 1;                               // merged relevance string, k bits (+ spill word)
+    const int mwords = (k + 31) / 32 + 1;
+    uint32_t *scratch = M + mwords + (mwords & 1);                // ap_finish: 8-byte aligned
+    const int qi = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    for (int u = tid; u < G * (nbins + 1); u += 256) {
+        const int g = u / (nbins + 1), b = u - g * (nbins + 1);
+        start[u] = (int32_t)min(cum[((int64_t)g * Q + qi) * (nbins + 1) + b], (uint32_t)kin);
+    }
+    for (int u = tid; u < mwords; u += 256) M[u] = 0;
+    __syncthreads();
+    if (need_out && wv == 1) {
+        int T = nbins - 1;
+        for (int c = 2; c >= 0; --c) {
+            const int b = 64 * c + lane;
+            uint32_t sb = 0;
+            if (b < nbins)
+                for (int g = 0; g < G; ++g) sb += cum[((int64_t)g * Q + qi) * (nbins + 1) + b + 1];
+            const uint64_t m = __ballot(b < nbins && sb >= (uint32_t)k);
+            if (m) T = 64 * c + __builtin_ctzll(m);
+        }
+        uint32_t nd = 0;
+        for (int g = lane; g < G; g += 64) nd = max(nd, cum[((int64_t)g * Q + qi) * (nbins + 1) + T + 1]);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) nd = max(nd, (uint32_t)__shfl_xor((int)nd, d, 64));
+        if (lane == 0) atomicMax(need_out, (int32_t)min(nd, 0x7fffffffu));
+    }
+    if (wv == 0) {   // totals per bin and their exclusive scan (up to 3 bins per lane)
+        uint32_t t[3] = {0, 0, 0};
+        const int b0 = 3 * lane;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (b0 + j < nbins)
+                for (int g = 0; g < G; ++g) t[j] += (uint32_t)(start[g * (nbins + 1) + b0 + j + 1] - start[g * (nbins + 1) + b0 + j]);
+        const uint32_t incl = wave_incl_scan_u32(t[0] + t[1] + t[2]);
+        const uint32_t excl = incl - (t[0] + t[1] + t[2]);
+        if (b0 < nbins) base[b0] = excl;
+        if (b0 + 1 < nbins) base[b0 + 1] = excl + t[0];
+        if (b0 + 2 < nbins) base[b0 + 2] = excl + t[0] + t[1];
+    }
+    __syncthreads();
+    for (int u = tid; u < G * nbins; u += 256) {                  // one run per (bin, shard)
+        const int b = u / G, g = u - b * G;
+        const int s0 = start[g * (nbins + 1) + b], n0 = start[g * (nbins + 1) + b + 1] - s0;
+        if (n0 <= 0) continue;
+        uint32_t dst = base[b];
+        for (int g2 = 0; g2 < g; ++g2) dst += (uint32_t)(start[g2 * (nbins + 1) + b + 1] - start[g2 * (nbins + 1) + b]);
+        if (dst >= (uint32_t)k) continue;
+        const int n = min(n0, k - (int)dst);
+        const uint32_t *src = relbits + ((int64_t)g * Q + qi) * w32;
+        for (int o = 0; o < n; o += 32) {
+            const int cnt = min(32, n - o), sp = s0 + o, sw = sp >> 5, sh = sp & 31;
+            uint32_t v = src[sw] >> sh;
+            if (sh && sw + 1 < w32) v |= src[sw + 1] << (32 - sh);
+            if (cnt < 32) v &= (1u << cnt) - 1u;
+            if (!v) continue;
+            const uint32_t dp = dst + (uint32_t)o, dw = dp >> 5, ds = dp & 31;
+            atomicOr(&M[dw], v << ds);
+            if (ds && (v >> (32 - ds))) atomicOr(&M[dw + 1], v >> (32 - ds));
+        }
+    }
+    __syncthreads();
+    const int R = (k + 255) / 256;
+    uint32_t mine = 0;
+    for (int r = 0; r < R; ++r) {
+        const int p = r * 256 + tid;
+        const bool rel = p < k && ((M[p >> 5] >> (p & 31)) & 1u);
+        mine |= (rel ? 1u : 0u) << r;
+        const uint64_t m = __ballot(rel);
+        if (lane == 0) scratch[r * 4 + wv] = (uint32_t)__popcll(m);
+    }
+    ap_finish<256>(mine, scratch, R, tid, ap + qi, nrel ? nrel + qi : nullptr, [] { __syncthreads(); });
+}
+}  // namespace wv
+
 extern "C" int wv_topk_merge_cum_need(const uint16_t *idx_local, const uint32_t *cum, int G, int Q, int kin, int64_t shard_rows,
                                       int32_t *idx_out, uint8_t *dist_out, int k, int nbits, int32_t *need_out, void *stream);
 
@@ -1080,6 +1169,44 @@ extern "C" int wv_hamming_shard_prefix(const uint64_t *q, const uint64_t *db, co
     WV_REQUIRE(k >= 1 && k <= N, "hamming_shard_prefix: k=%d must be in [1, N=%lld]", k, (long long)N);
     if (Q == 0) return WV_OK;
     return shard_call("hamming_shard_prefix", q, db, prepared, rows, cum, Q, N, nbits, k, workspace, workspace_bytes, stream);
+}
+
+extern "C" int wv_hamming_shard_relbits(const uint64_t *q, const void *prepared, const void *prepared_labels, const uint64_t *qlab,
+                                        uint64_t *relbits, uint32_t *cum, int Q, int64_t N, int nbits, int k, void *stream)
+{
+    WV_REQUIRE(q && prepared && prepared_labels && qlab && relbits && cum, "hamming_shard_relbits: null buffer");
+    WV_REQUIRE(Q >= 0 && N >= 1, "hamming_shard_relbits: bad shape Q=%d N=%lld", Q, (long long)N);
+    WV_REQUIRE(nbits >= 1 && nbits <= 128, "hamming_shard_relbits: nbits=%d (supported: 1..128)", nbits);
+    WV_REQUIRE(k >= 1 && k <= N, "hamming_shard_relbits: k=%d must be in [1, N=%lld]", k, (long long)N);
+    if (Q == 0) return WV_OK;
+    const int words = (nbits + 63) / 64;
+    int tpq = rank2_tpq(Q, N, k);
+    if (tpq == 64 && k > 32 * 64 && N <= kImg256MaxRows) tpq = 256;
+    if (!tpq || N > kImg256MaxRows || (tpq == 64 && N > kImg64MaxRows))
+        WV_FAIL(WV_ENOTSUP, "hamming_shard_relbits: %lld rows / k=%d are outside the windowed kernel", (long long)N, k);
+    const char *base = (const char *)prepared + align_up((int64_t)dist_prepared_bytes(N, words), 256);
+    const void *img = base + (tpq == 256 ? r2_off256(N, words) : r2_off64(N, words));
+    const int rc = rank2_launch(q, img, nullptr, nullptr, nullptr, Q, N, nbits, k, 0, cum, tpq, (hipStream_t)stream, prepared_labels,
+                                qlab, nullptr, nullptr, relbits);
+    if (rc > 0) WV_FAIL(WV_ENOTSUP, "hamming_shard_relbits: k=%d is outside the fused kernel", k);
+    return rc;
+}
+
+extern "C" int wv_merge_relbits_map(const uint64_t *relbits, const uint32_t *cum, int G, int Q, int kin, int k, int nbits, float *ap,
+                                    int32_t *nrel, int32_t *need_out, void *stream)
+{
+    WV_REQUIRE(relbits && cum && ap, "merge_relbits_map: null buffer");
+    WV_REQUIRE(G >= 1 && Q >= 0 && kin >= 1 && k >= 1, "merge_relbits_map: bad shape G=%d Q=%d kin=%d k=%d", G, Q, kin, k);
+    WV_REQUIRE(nbits >= 1 && nbits <= 128, "merge_relbits_map: nbits=%d (supported: 1..128)", nbits);
+    if (k > kApRounds * 256) WV_FAIL(WV_ENOTSUP, "merge_relbits_map: k=%d > %d", k, kApRounds * 256);
+    if (Q == 0) return WV_OK;
+    const int nbins = nbits + 1, w32 = 2 * (int)ceil_div(kin, 64), mwords = (k + 31) / 32 + 1;
+    const size_t lds = ((size_t)G * (nbins + 1) + nbins + 1 + mwords + (mwords & 1) + ap_scratch_dwords<256>() + 4) * 4;
+    WV_REQUIRE(lds <= 60 * 1024, "merge_relbits_map: too many shards (G=%d)", G);
+    hipLaunchKernelGGL(k_merge_relbits_ap, dim3(Q), dim3(256), lds, (hipStream_t)stream, reinterpret_cast<const uint32_t *>(relbits),
+                       cum, G, Q, kin, w32, k, nbins, ap, nrel, need_out);
+    WV_CHECK_LAUNCH("k_merge_relbits_ap");
+    return WV_OK;
 }
 
 extern "C" int wv_hamming_topk_rows16(const uint64_t *q, const uint64_t *db, const void *prepared, uint16_t *rows, int Q,

@@ -192,6 +192,55 @@ def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, works
     return (out[0], out[1], need) if return_need else out
 
 
+def sharded_hamming_map_at_k(q_local, qlab_local, db_shard, labels_shard, nbits, k, n_total, send_hint, group=None):
+    """mAP@k ingredients of THIS rank's queries against the row-sharded database, without a single list on the wire:
+    -> (ap float32 [Ql], nrel int32 [Ql], need int32 [1]) or None when the shape is outside the kernels (the caller then
+    uses sharded_hamming_topk + map_at_k: same numbers).
+
+    calculate_maphashing (accuracy_calculator.py:183-231) needs of a list entry only whether it is relevant.  So a shard
+    ranks every query against its rows as before, but what it sends per query is the RELEVANCE STRING of its `send_hint`
+    nearest rows (1 bit per entry; the shard knows its rows' labels, the queries' label words travel with their codes in
+    the one all_gather) plus its cumulative histogram; the receiver interleaves the strings bin by bin and evaluates the
+    merged string exactly as map_at_k evaluates a list.  Per step: one all_gather, one ranking pass per shard, two small
+    all_to_alls (133 + 264 bytes per query and shard at 8 GPUs instead of 2,128 + 264), one merge kernel.
+    q_local int64 [Ql, words]; qlab_local int64 [Ql, 1]; db_shard PreparedDB and labels_shard PreparedLabels of this rank's
+    rows; send_hint: the prefix length (as for sharded_hamming_topk: learn it from an exactly-sized list step, check the
+    returned `need` with exchange_ok)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        out = H.hamming_map_at_k(q_local, db_shard, labels_shard, qlab_local, nbits, k)
+        return None if out is None else (out[0], out[1], None)
+    rank = dist.get_rank(group)
+    Ql, words = q_local.shape
+    lo, hi, per = shard_bounds(n_total, world, rank)
+    n_local = hi - lo
+    if per > H.SHARD_ROWS_MAX or k > 8192 or qlab_local.shape[1] != 1 or nbits > 128 or send_hint is None:
+        return None                                      # decided from values every rank shares: no rank goes another way
+    dev = q_local.device
+    both = torch.cat([q_local, qlab_local], dim=1).contiguous()           # codes | label word: one collective
+    both_all = torch.empty((world * Ql, words + 1), dtype=both.dtype, device=dev)
+    _all_gather(both_all, both, group)
+    q_all, ql_all = both_all[:, :words].contiguous(), both_all[:, words:].contiguous()
+    send = max(1, min(min(k, per), int(send_hint)))
+    W = (send + 63) // 64
+    rb = torch.zeros((world * Ql, W), dtype=torch.int64, device=dev)
+    cum = torch.zeros((world * Ql, nbits + 2), dtype=torch.int32, device=dev)
+    if n_local > 0:
+        w = min(send, n_local)
+        got = H.hamming_shard_relbits(q_all, db_shard, labels_shard, ql_all, nbits, w)
+        if got is None:
+            raise RuntimeError("sharded_hamming_map_at_k: this shard is outside the fused kernel although the shared checks passed")
+        rb[:, :got[0].shape[1]] = got[0]
+        cum = got[1]
+    rb_r = torch.empty_like(rb)
+    _all_to_all(rb_r, rb, group)
+    cum_r = torch.empty_like(cum)
+    _all_to_all(cum_r, cum.contiguous(), group)
+    need = torch.zeros(1, dtype=torch.int32, device=dev)
+    ap, nrel = H.merge_relbits_map(rb_r.view(world, Ql, W), cum_r.view(world, Ql, nbits + 2), send, k, nbits, need_out=need)
+    return ap, nrel, need
+
+
 def exchange_ok(needs, send_hint, kin):
     """True when every `need` a hinted call returned fits the prefix length that was exchanged (one host read for
     the whole list; call it where the host synchronises anyway)."""

@@ -236,6 +236,21 @@ int wv_topk_merge_cum(const uint16_t *idx_local, const uint32_t *cum, int G, int
 int wv_topk_merge_cum_need(const uint16_t *idx_local, const uint32_t *cum, int G, int Q, int kin, int64_t shard_rows,
                            int32_t *idx_out, uint8_t *dist_out, int k, int nbits, int32_t *need_out, void *stream);
 
+/* Sharded mAP@k without lists on the wire (wvhash/parallel.py: sharded_hamming_map_at_k).  calculate_maphashing needs, of every
+ * list entry, only whether it is relevant: a shard therefore sends per query the RELEVANCE STRING of its k nearest rows (bit p
+ * = its p-th nearest row shares a label with the query; 1 bit per entry instead of a 16-bit row number) and its cumulative
+ * histogram; the receiver interleaves the strings of the G shards bin by bin (global order = distance, shard, position) and
+ * evaluates the merged string exactly as wv_map_at_k evaluates a list.
+ *   wv_hamming_shard_relbits  relbits uint64 [Q][ceil(k / 64)], cum uint32 [Q][nbits + 2]; prepared / prepared_labels: the
+ *                             shard's wv_db_prepare and wv_rank_labels_prepare blobs; qlab: label word of every query
+ *   wv_merge_relbits_map      relbits [G][Q][ceil(kin / 64)], cum [G][Q][nbits + 2] -> ap float32 [Q], nrel int32 [Q] (or NULL),
+ *                             need_out as in wv_topk_merge_cum_need
+ * WV_ENOTSUP outside the windowed kernel's range (shards of more than 32,768 rows, k > 8,192, wider labels). */
+int wv_hamming_shard_relbits(const uint64_t *q, const void *prepared, const void *prepared_labels, const uint64_t *qlab,
+                             uint64_t *relbits, uint32_t *cum, int Q, int64_t N, int nbits, int k, void *stream);
+int wv_merge_relbits_map(const uint64_t *relbits, const uint32_t *cum, int G, int Q, int kin, int k, int nbits, float *ap,
+                         int32_t *nrel, int32_t *need_out, void *stream);
+
 /* Ranking from a stored distance matrix row (same order as wv_hamming_topk). */
 int wv_rank_from_dist(const uint8_t *dist_matrix, int64_t ld_dist, int Q, int64_t N, int nbits,
                       int32_t *idx, uint8_t *dist, int k, void *stream);

@@ -35,8 +35,17 @@ def _worker(rank, world, port, out_dir):
         idx_h, d_h, need_h = parallel.sharded_hamming_topk(qp, shard, nbits, k, n_db, send_hint=hint, return_need=True)
         assert parallel.exchange_ok([need_h], hint, min(k, hi - lo + 1))
         full_idx, full_d = H.hamming_topk(H.pack_codes(q[rank * ql:(rank + 1) * ql].cuda()), H.pack_codes(r.cuda()), nbits, k)
+        # mAP without lists on the wire: relevance strings + histograms, merged on the receiving rank
+        qlp = H.pack_labels(labels_q[rank * ql:(rank + 1) * ql].cuda())
+        rlp = H.pack_labels(labels_r.cuda())
+        ap_ref, nrel_ref = H.map_at_k(full_idx, qlp, rlp)
+        map_ok = None
+        if prepared and hi - lo <= H.SHARD_ROWS_MAX:
+            got = parallel.sharded_hamming_map_at_k(qp, qlp, shard, H.PreparedLabels(rlp[lo:hi].contiguous()), nbits, k, n_db, hint)
+            ap, nrel, need_m = got
+            map_ok = (torch.equal(ap, ap_ref) and torch.equal(nrel, nrel_ref) and parallel.exchange_ok([need_m], hint, min(k, hi - lo + 1)))
         out[(n_db, nbits, k)] = (torch.equal(idx, full_idx) and torch.equal(d, full_d),
-                                 torch.equal(idx_h, full_idx) and torch.equal(d_h, full_d), int(need.item()), hint)
+                                 torch.equal(idx_h, full_idx) and torch.equal(d_h, full_d), int(need.item()), hint, map_ok)
     torch.save(out, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -48,9 +57,11 @@ def test_two_ranks_on_one_gpu_real_kernels(tmp_path):
     for rank in range(2):
         got = torch.load(os.path.join(tmp_path, f"r{rank}.pt"))
         assert len(got) == 3
-        for key, (exact, hinted, need, hint) in got.items():
+        for key, (exact, hinted, need, hint, map_ok) in got.items():
             assert exact and hinted, (rank, key)
             assert need <= hint
+            assert map_ok is not False, (rank, key)                  # None: shape not taken by the relevance-string path
+        assert sum(v[4] is True for v in got.values()) >= 1
 
 
 def _eval_worker(rank, world, port, out_dir):

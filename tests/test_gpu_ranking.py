@@ -624,3 +624,48 @@ def test_fused_map_at_k_refuses_what_it_cannot_do():
     assert H.hamming_map_at_k(qp, prep, wide, H.pack_labels(synth.multi_hot_labels(4, 100, 0.1, 2).cuda()), 64, 10) is None
     big = H.PreparedLabels(torch.zeros((40000, 1), dtype=torch.int64, device="cuda"))               # more rows than the kernel takes
     assert not big.ok
+
+
+@pytest.mark.parametrize("Q,N,nbits,k,G,Lc", [(37, 11000, 64, 3000, 8, 38), (19, 999, 16, 999, 3, 10), (4100, 5000, 64, 1200, 8, 38),
+                                              (21, 20000, 128, 5000, 7, 64), (9, 40, 32, 7, 5, 3), (64, 25000, 64, 5000, 8, 38)])
+def test_sharded_map_from_relevance_strings_equals_unsharded(Q, N, nbits, k, G, Lc):
+    """What the ranks of sharded_hamming_map_at_k run, for G shards on one GPU: wv_hamming_shard_relbits per shard (relevance
+    string of the prefix + histograms) -> wv_merge_relbits_map.  AP and hit counts must equal map_at_k of the unsharded
+    ranking bit for bit, the reported need must be the true one, and a prefix one entry too short must be flagged."""
+    ql, rl = synth.multi_hot_labels(Q, Lc, 0.12, 21), synth.multi_hot_labels(N, Lc, 0.12, 22)
+    q, r = (synth.structured_codes(ql, nbits, 3, 4), synth.structured_codes(rl, nbits, 3, 5)) if Lc >= 10 else \
+        _spread_codes(Q, N, nbits, seed=N + G)
+    qp, rp = H.pack_codes(q.cuda()), H.pack_codes(r.cuda())
+    qlp, rlp = H.pack_labels(ql.cuda()), H.pack_labels(rl.cuda())
+    idx, _ = H.hamming_topk(qp, rp, nbits, k, want_dist=False)
+    ap_ref, nrel_ref = H.map_at_k(idx, qlp, rlp)
+    per = (N + G - 1) // G
+    shards = []
+    for g in range(G):
+        lo, hi = min(N, g * per), min(N, (g + 1) * per)
+        shards.append((lo, hi, H.PreparedDB(rp[lo:hi].contiguous(), nbits) if hi > lo else None,
+                       H.PreparedLabels(rlp[lo:hi].contiguous()) if hi > lo else None))
+    cums = torch.stack([H.hamming_hist(qp, db, nbits) if db is not None else
+                        torch.zeros((Q, nbits + 2), dtype=torch.int32, device="cuda") for _, _, db, _ in shards])
+    T = (cums.sum(0)[:, 1:] >= k).int().argmax(dim=1)
+    need = int(torch.gather(cums, 2, (T + 1).view(1, Q, 1).expand(G, Q, 1).long()).max().item())
+    for send, exact in ((min(min(k, per), need), True), (max(1, need - 1), need == 1)):
+        W = (send + 63) // 64
+        rbs, cs = [], []
+        for lo, hi, db, lab in shards:
+            rb = torch.zeros((Q, W), dtype=torch.int64, device="cuda")
+            c = torch.zeros((Q, nbits + 2), dtype=torch.int32, device="cuda")
+            if db is not None:
+                w = min(send, hi - lo)
+                got = H.hamming_shard_relbits(qp, db, lab, qlp, nbits, w)
+                assert got is not None
+                rb[:, :got[0].shape[1]] = got[0]
+                c = got[1]
+            rbs.append(rb)
+            cs.append(c)
+        assert torch.equal(torch.stack(cs), cums)
+        owed = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ap, nrel = H.merge_relbits_map(torch.stack(rbs), torch.stack(cs), send, k, nbits, need_out=owed)
+        assert int(owed.item()) == need and (need <= send) == exact
+        if exact:
+            assert torch.equal(nrel, nrel_ref) and torch.equal(ap, ap_ref)

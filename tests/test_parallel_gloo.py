@@ -68,6 +68,49 @@ def _fake_shard_prefix(q_packed, db, nbits, k, workspace=None):
     return _fake_rows16(q_packed, db, nbits, k), _fake_hist(q_packed, db, nbits)
 
 
+def _label_words(rows):
+    """0/1 label rows [n, Lc <= 62] -> one int64 word per row, bit c = class c (pack_labels' layout)."""
+    return (rows.long() << torch.arange(rows.shape[1])).sum(1, keepdim=True)
+
+
+def _fake_shard_relbits(q_packed, db, labels, qlab_packed, nbits, k):
+    """db: packed codes of the shard; labels: its label words [n, 1]; qlab_packed: label words of the queries [Q, 1]."""
+    from oracle import ranking
+    idx, _ = ranking.hamming_topk_stable(_unpack(q_packed, nbits), _unpack(db, nbits), k)
+    rel = (labels[:, 0][idx] & qlab_packed) != 0                              # [Q, k]
+    W = (k + 63) // 64
+    bits = torch.zeros((rel.shape[0], W * 64), dtype=torch.long)
+    bits[:, :k] = rel.long()
+    w = bits.reshape(-1, W, 64)
+    sh = torch.arange(64)
+    words = (w[..., :63] << sh[:63]).sum(-1) + torch.where(w[..., 63] > 0, torch.tensor(-2 ** 63), torch.tensor(0))
+    return words, _fake_hist(q_packed, db, nbits)
+
+
+def _fake_merge_relbits(relbits, cum, kin, k, nbits, need_out=None):
+    """Expand every shard's string to one 0/1 entry per list position, merge by (distance, shard, position), AP as the
+    reference computes it (fp32 quotients, mean over the hits)."""
+    G, Q, W = relbits.shape
+    if need_out is not None:
+        T = (cum.sum(0)[:, 1:] >= k).int().argmax(dim=1)
+        owed = torch.gather(cum, 2, (T + 1).view(1, Q, 1).expand(G, Q, 1).long()).max()
+        need_out.copy_(torch.maximum(need_out, owed.reshape(1).int()))
+    sh = torch.arange(64)
+    bits = ((relbits.unsqueeze(-1) >> sh) & 1).reshape(G, Q, W * 64)[:, :, :kin]
+    pos = torch.arange(kin).view(1, 1, kin)
+    d = (cum[:, :, 1:nbits + 2].unsqueeze(-1) <= pos.unsqueeze(2)).sum(2)
+    d = torch.where(pos < cum[:, :, nbits + 1:nbits + 2].clamp(max=kin), d, torch.full_like(d, nbits + 1))
+    key = d.permute(1, 0, 2).reshape(Q, G * kin)
+    rel = bits.permute(1, 0, 2).reshape(Q, G * kin)
+    order = torch.argsort(key, dim=1, stable=True)[:, :k]
+    rel = torch.gather(rel, 1, order).float()
+    hits = rel.cumsum(1)
+    quo = (hits / torch.arange(1, rel.shape[1] + 1).float()) * rel
+    nrel = rel.sum(1)
+    ap = torch.where(nrel > 0, quo.double().sum(1) / nrel.clamp(min=1).double(), torch.zeros(Q, dtype=torch.float64))
+    return ap.float(), nrel.int()
+
+
 def _fake_merge_cum(idx_local, cum, shard_rows, k, nbits, need_out=None):
     """Expand the compact form (16-bit local rows + per-shard cumulative histograms) and merge as above."""
     G, Q, kin = idx_local.shape
@@ -117,6 +160,58 @@ def _worker(rank, world, port, cases, nbits, ql, out_dir):
     torch.save(out, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _map_worker(rank, world, port, cases, nbits, ql, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "image-retrieval-wavelet_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wvhash import parallel, synth
+    from wvhash.engine import hamming as H
+    H.hamming_shard_relbits, H.merge_relbits_map = _fake_shard_relbits, _fake_merge_relbits
+    out = {}
+    for n_db, k in cases:
+        q_all, r = synth.random_codes(world * ql, n_db, nbits, seed=3)
+        ql_all, rl = synth.multi_hot_labels(world * ql, 12, 0.2, 5), synth.multi_hot_labels(n_db, 12, 0.2, 6)
+        lo, hi, per = parallel.shard_bounds(n_db, world, rank)
+        sl = slice(rank * ql, (rank + 1) * ql)
+        for hint in (min(k, per), 1):
+            ap, nrel, need = parallel.sharded_hamming_map_at_k(_pack(q_all[sl]), _label_words(ql_all[sl]), _pack(r[lo:hi]),
+                                                               _label_words(rl[lo:hi]), nbits, k, n_db, hint)
+            out[(n_db, k, hint)] = (ap, nrel, need, max(1, min(min(k, per), hint)))
+    torch.save(out, os.path.join(out_dir, f"m{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,cases", [(2, [(1000, 300), (1001, 600), (64, 10)]), (3, [(500, 500), (77, 40)])])
+def test_sharded_map_exchange_of_relevance_strings(tmp_path, world, cases):
+    """The exchange behind sharded_hamming_map_at_k (codes + label words in one all_gather, relevance strings + histograms
+    through two all_to_alls, merge on the receiving rank) with CPU stand-ins for the two kernels: AP and hit counts of the
+    unsharded oracle ranking whenever the reported need fits the prefix that was sent; a prefix of one entry is flagged."""
+    from oracle import ranking
+    from wvhash import synth
+    nbits, ql = 64, 5
+    port = 31500 + (os.getpid() + world * 11) % 2000
+    mp.spawn(_map_worker, args=(world, port, cases, nbits, ql, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        got = torch.load(os.path.join(tmp_path, f"m{rank}.pt"))
+        for n_db, k in cases:
+            q_all, r = synth.random_codes(world * ql, n_db, nbits, seed=3)
+            ql_all, rl = synth.multi_hot_labels(world * ql, 12, 0.2, 5), synth.multi_hot_labels(n_db, 12, 0.2, 6)
+            ref_idx, _ = ranking.hamming_topk_stable(q_all, r, k)
+            sl = slice(rank * ql, (rank + 1) * ql)
+            rel = ((rl[ref_idx[sl]] * ql_all[sl].unsqueeze(1)).sum(-1) > 0).float()
+            hits = rel.cumsum(1)
+            want = ((hits / torch.arange(1, k + 1).float()) * rel).double().sum(1) / rel.sum(1).clamp(min=1).double()
+            per = (n_db + world - 1) // world
+            for hint in (min(k, per), 1):
+                ap, nrel, need, send = got[(n_db, k, hint)]
+                if int(need.item()) <= send:
+                    assert torch.equal(nrel.long(), rel.sum(1).long()) and (ap.double() - want).abs().max() < 1e-6
+                else:
+                    assert hint == 1
 
 
 # one process group per world size (spawning costs a torch import per rank), several shapes inside:
