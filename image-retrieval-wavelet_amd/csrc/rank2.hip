@@ -97,6 +97,8 @@ struct Rank2Ap {
     float *ap;               // [Q]
     int32_t *nrel;           // [Q] relevant entries among the k (or NULL)
     uint64_t *relbits;       // [Q][ceil(k / 64)] instead of ap: the relevance string of the list (sharded mAP)
+    int64_t relbits_ld;      // row pitch of relbits in uint64 (0 = ceil(k / 64))
+    int64_t cum_ld;          // row pitch of the histograms in uint32 (0 = nbits + 2): relbits and cum may share one wire buffer
 };
 
 // words of the relevance bitmap: one bit per database row
@@ -637,9 +639,10 @@ __global__ __launch_bounds__(256, rank2_min_waves(NC, QB)) void k_rank_window(co
                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)lw);
                 rank2_one_query<TPQ, NC, true>(dc[qq], dmin[qq], N, C, nbins, k, idx_offset, idx ? idx + (int64_t)qi * k : nullptr,
                                                rows16 ? rows16 + (int64_t)qi * k : nullptr, dist ? dist + (int64_t)qi * k : nullptr,
-                                               cum ? cum + (int64_t)qi * (nbins + 1) : nullptr, lds, t, apx.cls, ql,
-                                               apx.ap ? apx.ap + qi : nullptr, apx.nrel ? apx.nrel + qi : nullptr,
-                                               apx.relbits ? apx.relbits + (int64_t)qi * ((k + 63) / 64) : nullptr);
+                                               cum ? cum + (int64_t)qi * (apx.cum_ld ? apx.cum_ld : nbins + 1) : nullptr, lds, t,
+                                               apx.cls, ql, apx.ap ? apx.ap + qi : nullptr, apx.nrel ? apx.nrel + qi : nullptr,
+                                               apx.relbits ? apx.relbits + (int64_t)qi * (apx.relbits_ld ? apx.relbits_ld : (k + 63) / 64)
+                                                           : nullptr);
             } else {
                 rank2_one_query<TPQ, NC>(dc[qq], dmin[qq], N, C, nbins, k, idx_offset, idx ? idx + (int64_t)qi * k : nullptr,
                                          rows16 ? rows16 + (int64_t)qi * k : nullptr, dist ? dist + (int64_t)qi * k : nullptr,
@@ -735,10 +738,10 @@ static int launch_rank2_t(const uint64_t *q, const void *img, int32_t *idx, uint
 // idx (int32 global indices) or rows16 (16-bit local row numbers) receives the list; k == 0: histogram only
 int rank2_launch(const uint64_t *q, const void *img, int32_t *idx, uint16_t *rows16, uint8_t *dist, int Q, int64_t N, int nbits,
                  int k, int64_t idx_offset, uint32_t *cum, int tpq, hipStream_t st, const void *lab_img, const uint64_t *qlab,
-                 float *ap, int32_t *nrel, uint64_t *relbits)
+                 float *ap, int32_t *nrel, uint64_t *relbits, int64_t relbits_ld, int64_t cum_ld)
 {
     const int nbins = nbits + 1, words = (nbits + 63) / 64;
-    Rank2Ap apx{reinterpret_cast<const uint32_t *>(lab_img), qlab, ap, nrel, relbits};
+    Rank2Ap apx{reinterpret_cast<const uint32_t *>(lab_img), qlab, ap, nrel, relbits, relbits_ld, cum_ld};
     if (ap || relbits) {
         if (!lab_img || !qlab || k < 1 || k > kApRounds * tpq) return 1;                     // the AP walk keeps <= 32 positions per thread
         const size_t per_g = tpq == 64 ? 4 * rank2_lds_bytes_per_query<64>(k, rank2_bitmap_words(N))

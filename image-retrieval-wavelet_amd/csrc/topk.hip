@@ -31,7 +31,8 @@ int rank2_labels_prepare(const uint64_t *dblab, void *cls, int64_t N, hipStream_
 // lab_img (the class-major label bit matrix) / qlab / ap / nrel: average precision of the list (wv_hamming_map_at_k); all NULL otherwise
 int rank2_launch(const uint64_t *q, const void *img, int32_t *idx, uint16_t *rows16, uint8_t *dist, int Q, int64_t N, int nbits,
                  int k, int64_t idx_offset, uint32_t *cum, int tpq, hipStream_t st, const void *lab_img = nullptr,
-                 const uint64_t *qlab = nullptr, float *ap = nullptr, int32_t *nrel = nullptr, uint64_t *relbits = nullptr);
+                 const uint64_t *qlab = nullptr, float *ap = nullptr, int32_t *nrel = nullptr, uint64_t *relbits = nullptr,
+                 int64_t relbits_ld = 0, int64_t cum_ld = 0);
 // the one-wave-per-query image exists for databases (shards) of at most this many rows
 constexpr int64_t kImg64MaxRows = 64 * 64;
 // images of the windowed kernel exist for databases it can take at all (16-bit item numbers, <= 128 items per thread)
@@ -897,7 +898,7 @@ namespace wv {
 __global__ __launch_bounds__(256) void k_merge_relbits_ap(const uint32_t *__restrict__ relbits, const uint32_t *__restrict__ cum,
                                                           int G, int Q, int kin, int w32, int k, int nbins,
                                                           float *__restrict__ ap, int32_t *__restrict__ nrel,
-                                                          int32_t *__restrict__ need_out)
+                                                          int32_t *__restrict__ need_out, int64_t rb_ld32, int64_t cum_ld)
 {
     extern __shared__ uint4 lds4[];
     int32_t *start = reinterpret_cast<int32_t *>(lds4);           // [G][nbins + 1]: first position with dist >= b
@@ -908,7 +909,7 @@ __global__ __launch_bounds__(256) void k_merge_relbits_ap(const uint32_t *__rest
     const int qi = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     for (int u = tid; u < G * (nbins + 1); u += 256) {
         const int g = u / (nbins + 1), b = u - g * (nbins + 1);
-        start[u] = (int32_t)min(cum[((int64_t)g * Q + qi) * (nbins + 1) + b], (uint32_t)kin);
+        start[u] = (int32_t)min(cum[((int64_t)g * Q + qi) * cum_ld + b], (uint32_t)kin);
     }
     for (int u = tid; u < mwords; u += 256) M[u] = 0;
     __syncthreads();
@@ -918,12 +919,12 @@ __global__ __launch_bounds__(256) void k_merge_relbits_ap(const uint32_t *__rest
             const int b = 64 * c + lane;
             uint32_t sb = 0;
             if (b < nbins)
-                for (int g = 0; g < G; ++g) sb += cum[((int64_t)g * Q + qi) * (nbins + 1) + b + 1];
+                for (int g = 0; g < G; ++g) sb += cum[((int64_t)g * Q + qi) * cum_ld + b + 1];
             const uint64_t m = __ballot(b < nbins && sb >= (uint32_t)k);
             if (m) T = 64 * c + __builtin_ctzll(m);
         }
         uint32_t nd = 0;
-        for (int g = lane; g < G; g += 64) nd = max(nd, cum[((int64_t)g * Q + qi) * (nbins + 1) + T + 1]);
+        for (int g = lane; g < G; g += 64) nd = max(nd, cum[((int64_t)g * Q + qi) * cum_ld + T + 1]);
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) nd = max(nd, (uint32_t)__shfl_xor((int)nd, d, 64));
         if (lane == 0) atomicMax(need_out, (int32_t)min(nd, 0x7fffffffu));
@@ -950,7 +951,7 @@ __global__ __launch_bounds__(256) void k_merge_relbits_ap(const uint32_t *__rest
         for (int g2 = 0; g2 < g; ++g2) dst += (uint32_t)(start[g2 * (nbins + 1) + b + 1] - start[g2 * (nbins + 1) + b]);
         if (dst >= (uint32_t)k) continue;
         const int n = min(n0, k - (int)dst);
-        const uint32_t *src = relbits + ((int64_t)g * Q + qi) * w32;
+        const uint32_t *src = relbits + ((int64_t)g * Q + qi) * rb_ld32;
         for (int o = 0; o < n; o += 32) {
             const int cnt = min(32, n - o), sp = s0 + o, sw = sp >> 5, sh = sp & 31;
             uint32_t v = src[sw] >> sh;
@@ -1172,8 +1173,11 @@ extern "C" int wv_hamming_shard_prefix(const uint64_t *q, const uint64_t *db, co
 }
 
 extern "C" int wv_hamming_shard_relbits(const uint64_t *q, const void *prepared, const void *prepared_labels, const uint64_t *qlab,
-                                        uint64_t *relbits, uint32_t *cum, int Q, int64_t N, int nbits, int k, void *stream)
+                                        uint64_t *relbits, int64_t relbits_ld, uint32_t *cum, int64_t cum_ld, int Q, int64_t N,
+                                        int nbits, int k, void *stream)
 {
+    WV_REQUIRE((relbits_ld == 0 || relbits_ld >= (k + 63) / 64) && (cum_ld == 0 || cum_ld >= nbits + 2),
+               "hamming_shard_relbits: row pitches %lld / %lld too small", (long long)relbits_ld, (long long)cum_ld);
     WV_REQUIRE(q && prepared && prepared_labels && qlab && relbits && cum, "hamming_shard_relbits: null buffer");
     WV_REQUIRE(Q >= 0 && N >= 1, "hamming_shard_relbits: bad shape Q=%d N=%lld", Q, (long long)N);
     WV_REQUIRE(nbits >= 1 && nbits <= 128, "hamming_shard_relbits: nbits=%d (supported: 1..128)", nbits);
@@ -1187,14 +1191,16 @@ extern "C" int wv_hamming_shard_relbits(const uint64_t *q, const void *prepared,
     const char *base = (const char *)prepared + align_up((int64_t)dist_prepared_bytes(N, words), 256);
     const void *img = base + (tpq == 256 ? r2_off256(N, words) : r2_off64(N, words));
     const int rc = rank2_launch(q, img, nullptr, nullptr, nullptr, Q, N, nbits, k, 0, cum, tpq, (hipStream_t)stream, prepared_labels,
-                                qlab, nullptr, nullptr, relbits);
+                                qlab, nullptr, nullptr, relbits, relbits_ld, cum_ld);
     if (rc > 0) WV_FAIL(WV_ENOTSUP, "hamming_shard_relbits: k=%d is outside the fused kernel", k);
     return rc;
 }
 
-extern "C" int wv_merge_relbits_map(const uint64_t *relbits, const uint32_t *cum, int G, int Q, int kin, int k, int nbits, float *ap,
-                                    int32_t *nrel, int32_t *need_out, void *stream)
+extern "C" int wv_merge_relbits_map(const uint64_t *relbits, int64_t relbits_ld, const uint32_t *cum, int64_t cum_ld, int G, int Q,
+                                    int kin, int k, int nbits, float *ap, int32_t *nrel, int32_t *need_out, void *stream)
 {
+    WV_REQUIRE((relbits_ld == 0 || relbits_ld >= (kin + 63) / 64) && (cum_ld == 0 || cum_ld >= nbits + 2),
+               "merge_relbits_map: row pitches %lld / %lld too small", (long long)relbits_ld, (long long)cum_ld);
     WV_REQUIRE(relbits && cum && ap, "merge_relbits_map: null buffer");
     WV_REQUIRE(G >= 1 && Q >= 0 && kin >= 1 && k >= 1, "merge_relbits_map: bad shape G=%d Q=%d kin=%d k=%d", G, Q, kin, k);
     WV_REQUIRE(nbits >= 1 && nbits <= 128, "merge_relbits_map: nbits=%d (supported: 1..128)", nbits);
@@ -1204,7 +1210,8 @@ extern "C" int wv_merge_relbits_map(const uint64_t *relbits, const uint32_t *cum
     const size_t lds = ((size_t)G * (nbins + 1) + nbins + 1 + mwords + (mwords & 1) + ap_scratch_dwords<256>() + 4) * 4;
     WV_REQUIRE(lds <= 60 * 1024, "merge_relbits_map: too many shards (G=%d)", G);
     hipLaunchKernelGGL(k_merge_relbits_ap, dim3(Q), dim3(256), lds, (hipStream_t)stream, reinterpret_cast<const uint32_t *>(relbits),
-                       cum, G, Q, kin, w32, k, nbins, ap, nrel, need_out);
+                       cum, G, Q, kin, w32, k, nbins, ap, nrel, need_out, relbits_ld ? 2 * relbits_ld : (int64_t)w32,
+                       cum_ld ? cum_ld : (int64_t)(nbins + 1));
     WV_CHECK_LAUNCH("k_merge_relbits_ap");
     return WV_OK;
 }

@@ -77,8 +77,8 @@ SIGNATURES = {
     "wv_hamming_map_at_k": (_i, [_vp, _vp, _vp, _vp, _i, ctypes.c_int64, _i, _i, _vp, _vp, _vp]),
     "wv_hamming_hist": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _sz, _vp]),
     "wv_hamming_topk_rows16": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _sz, _vp]),
-    "wv_hamming_shard_relbits": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
-    "wv_merge_relbits_map": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "wv_hamming_shard_relbits": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i64, _i, _i, _vp]),
+    "wv_merge_relbits_map": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "wv_hamming_shard_prefix": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _sz, _vp]),
     "wv_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
     "wv_rank_from_dist": (_i, [_vp, _i64, _i, _i64, _i, _vp, _vp, _i, _vp]),

@@ -365,10 +365,18 @@ def hamming_map_at_k(q_packed, db, labels, qlab_packed, nbits, k):
     return ap, nrel
 
 
-def hamming_shard_relbits(q_packed, db, labels, qlab_packed, nbits, k):
-    """What a shard contributes to the sharded mAP: per query the relevance string of its k nearest rows (int64 storage of
-    uint64 words [Q, ceil(k / 64)], bit p = the p-th nearest row shares a label with the query) and its cumulative distance
-    histogram (int32 [Q, nbits + 2]).  None when the shape is outside the fused kernel."""
+def relbits_wire_words(kin, nbits):
+    """int64 words per (query, shard) row of the sharded-mAP wire buffer: [histogram: nbits + 2 int32, padded to 8 bytes |
+    relevance string: ceil(kin / 64) uint64]."""
+    return (nbits + 3) // 2 + (kin + 63) // 64
+
+
+def hamming_shard_relbits(q_packed, db, labels, qlab_packed, nbits, k, wire=None, kin=None):
+    """What a shard contributes to the sharded mAP: per query the relevance string of its k nearest rows (bit p = the p-th
+    nearest row shares a label with the query) and its cumulative distance histogram, side by side in ONE int64 buffer
+    [Q, relbits_wire_words(kin, nbits)] (kin >= k: the prefix length the ranks agreed on; a shard with fewer rows leaves the
+    tail of the string zero) -- a single all_to_all moves both.  `wire`: preallocated (zeroed) buffer.
+    -> wire, or None when the shape is outside the fused kernel."""
     lib = _lib.require_gpu()
     if not isinstance(db, PreparedDB) or not isinstance(labels, PreparedLabels):
         raise TypeError("hamming_shard_relbits: needs a PreparedDB and PreparedLabels")
@@ -377,37 +385,49 @@ def hamming_shard_relbits(q_packed, db, labels, qlab_packed, nbits, k):
         raise ValueError("hamming_shard_relbits: query / database / label shapes disagree")
     if not labels.ok or qlab_packed.shape[1] != 1 or nbits > 128 or not 1 <= k <= db.N:
         return None
+    kin = k if kin is None else kin
     dev = q_packed.device
-    rb = torch.empty((Q, (k + 63) // 64), dtype=torch.int64, device=dev)
-    cum = torch.empty((Q, nbits + 2), dtype=torch.int32, device=dev)
+    ld = relbits_wire_words(kin, nbits)
+    if wire is None:
+        wire = torch.zeros((Q, ld), dtype=torch.int64, device=dev)
+    elif tuple(wire.shape) != (Q, ld) or wire.dtype != torch.int64 or not wire.is_contiguous():
+        raise ValueError("hamming_shard_relbits: wire buffer of the wrong shape")
     if Q:
+        hist_words = (nbits + 3) // 2
         with torch.cuda.device(dev):
             rc = lib.wv_hamming_shard_relbits(_lib.ptr(q_packed.contiguous()), _lib.ptr(db.blob), _lib.ptr(labels.blob),
-                                              _lib.ptr(qlab_packed.contiguous()), _lib.ptr(rb), _lib.ptr(cum), Q, db.N, nbits, k,
-                                              _lib.stream_ptr())
+                                              _lib.ptr(qlab_packed.contiguous()), wire.data_ptr() + 8 * hist_words, ld,
+                                              wire.data_ptr(), 2 * ld, Q, db.N, nbits, k, _lib.stream_ptr())
             if rc == -95:      # WV_ENOTSUP
                 return None
             _lib.check(rc, "wv_hamming_shard_relbits")
-    return rb, cum
+    return wire
 
 
-def merge_relbits_map(relbits, cum, kin, k, nbits, need_out=None):
-    """relbits int64 [G, Q, ceil(kin / 64)], cum int32 [G, Q, nbits + 2] of G contiguous row shards in rank order ->
-    (ap float32 [Q], nrel int32 [Q]) of the merged top-k lists, equal to map_at_k of the merged lists.  need_out as in
-    topk_merge_cum."""
+def merge_relbits_map(wire, kin, k, nbits, need_out=None):
+    """wire int64 [G, Q, relbits_wire_words(kin, nbits)] -- the rows hamming_shard_relbits made on G contiguous row shards in
+    rank order -> (ap float32 [Q], nrel int32 [Q]) of the merged top-k lists, equal to map_at_k of the merged lists.
+    need_out as in topk_merge_cum."""
     lib = _lib.require_gpu()
-    G, Q, W = relbits.shape
-    if relbits.dtype != torch.int64 or cum.dtype != torch.int32 or tuple(cum.shape) != (G, Q, nbits + 2) or W != (kin + 63) // 64:
-        raise ValueError("merge_relbits_map: expected int64 [G,Q,ceil(kin/64)] strings and int32 [G,Q,nbits+2] histograms")
-    relbits, cum = relbits.contiguous(), cum.contiguous()
-    ap = torch.empty(Q, dtype=torch.float32, device=relbits.device)
-    nrel = torch.empty(Q, dtype=torch.int32, device=relbits.device)
+    G, Q, ld = wire.shape
+    if wire.dtype != torch.int64 or ld != relbits_wire_words(kin, nbits):
+        raise ValueError("merge_relbits_map: expected the int64 [G, Q, relbits_wire_words(kin, nbits)] wire buffer")
+    wire = wire.contiguous()
+    ap = torch.empty(Q, dtype=torch.float32, device=wire.device)
+    nrel = torch.empty(Q, dtype=torch.int32, device=wire.device)
     if Q:
-        with torch.cuda.device(relbits.device):
-            rc = lib.wv_merge_relbits_map(_lib.ptr(relbits), _lib.ptr(cum), G, Q, kin, k, nbits, _lib.ptr(ap), _lib.ptr(nrel),
-                                          _lib.ptr(need_out) if need_out is not None else None, _lib.stream_ptr())
+        hist_words = (nbits + 3) // 2
+        with torch.cuda.device(wire.device):
+            rc = lib.wv_merge_relbits_map(wire.data_ptr() + 8 * hist_words, ld, wire.data_ptr(), 2 * ld, G, Q, kin, k, nbits,
+                                          _lib.ptr(ap), _lib.ptr(nrel), _lib.ptr(need_out) if need_out is not None else None,
+                                          _lib.stream_ptr())
             _lib.check(rc, "wv_merge_relbits_map")
     return ap, nrel
+
+
+def wire_histograms(wire, nbits):
+    """int32 [.., nbits + 2] view of the histograms inside a wire buffer (tests, diagnostics)."""
+    return wire.view(torch.int32).reshape(*wire.shape[:-1], 2 * wire.shape[-1])[..., :nbits + 2]
 
 
 def hit_prefix(idx, qlab_packed, dblab_packed):

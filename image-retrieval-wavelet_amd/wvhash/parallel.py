@@ -201,8 +201,9 @@ def sharded_hamming_map_at_k(q_local, qlab_local, db_shard, labels_shard, nbits,
     ranks every query against its rows as before, but what it sends per query is the RELEVANCE STRING of its `send_hint`
     nearest rows (1 bit per entry; the shard knows its rows' labels, the queries' label words travel with their codes in
     the one all_gather) plus its cumulative histogram; the receiver interleaves the strings bin by bin and evaluates the
-    merged string exactly as map_at_k evaluates a list.  Per step: one all_gather, one ranking pass per shard, two small
-    all_to_alls (133 + 264 bytes per query and shard at 8 GPUs instead of 2,128 + 264), one merge kernel.
+    merged string exactly as map_at_k evaluates a list.  Per step: one all_gather, one ranking pass per shard, ONE small
+    all_to_all (histogram and string side by side: 264 + 136 bytes per query and shard at 8 GPUs instead of 264 + 2,128 in
+    two), one merge kernel.
     q_local int64 [Ql, words]; qlab_local int64 [Ql, 1]; db_shard PreparedDB and labels_shard PreparedLabels of this rank's
     rows; send_hint: the prefix length (as for sharded_hamming_topk: learn it from an exactly-sized list step, check the
     returned `need` with exchange_ok)."""
@@ -222,22 +223,16 @@ def sharded_hamming_map_at_k(q_local, qlab_local, db_shard, labels_shard, nbits,
     _all_gather(both_all, both, group)
     q_all, ql_all = both_all[:, :words].contiguous(), both_all[:, words:].contiguous()
     send = max(1, min(min(k, per), int(send_hint)))
-    W = (send + 63) // 64
-    rb = torch.zeros((world * Ql, W), dtype=torch.int64, device=dev)
-    cum = torch.zeros((world * Ql, nbits + 2), dtype=torch.int32, device=dev)
+    wire = torch.zeros((world * Ql, H.relbits_wire_words(send, nbits)), dtype=torch.int64, device=dev)
     if n_local > 0:
-        w = min(send, n_local)
-        got = H.hamming_shard_relbits(q_all, db_shard, labels_shard, ql_all, nbits, w)
+        got = H.hamming_shard_relbits(q_all, db_shard, labels_shard, ql_all, nbits, min(send, n_local), wire=wire, kin=send)
         if got is None:
             raise RuntimeError("sharded_hamming_map_at_k: this shard is outside the fused kernel although the shared checks passed")
-        rb[:, :got[0].shape[1]] = got[0]
-        cum = got[1]
-    rb_r = torch.empty_like(rb)
-    _all_to_all(rb_r, rb, group)
-    cum_r = torch.empty_like(cum)
-    _all_to_all(cum_r, cum.contiguous(), group)
+        wire = got
+    wire_r = torch.empty_like(wire)
+    _all_to_all(wire_r, wire, group)                      # histogram + relevance string of a (query, shard) side by side
     need = torch.zeros(1, dtype=torch.int32, device=dev)
-    ap, nrel = H.merge_relbits_map(rb_r.view(world, Ql, W), cum_r.view(world, Ql, nbits + 2), send, k, nbits, need_out=need)
+    ap, nrel = H.merge_relbits_map(wire_r.view(world, Ql, -1), send, k, nbits, need_out=need)
     return ap, nrel, need
 
 

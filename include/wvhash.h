@@ -245,11 +245,14 @@ int wv_topk_merge_cum_need(const uint16_t *idx_local, const uint32_t *cum, int G
  *                             shard's wv_db_prepare and wv_rank_labels_prepare blobs; qlab: label word of every query
  *   wv_merge_relbits_map      relbits [G][Q][ceil(kin / 64)], cum [G][Q][nbits + 2] -> ap float32 [Q], nrel int32 [Q] (or NULL),
  *                             need_out as in wv_topk_merge_cum_need
+ * relbits_ld / cum_ld: row pitches in uint64 / uint32 units (0 = tight): string and histogram of a (query, shard) may lie side
+ * by side in ONE wire buffer, so that a single all_to_all moves both.
  * WV_ENOTSUP outside the windowed kernel's range (shards of more than 32,768 rows, k > 8,192, wider labels). */
 int wv_hamming_shard_relbits(const uint64_t *q, const void *prepared, const void *prepared_labels, const uint64_t *qlab,
-                             uint64_t *relbits, uint32_t *cum, int Q, int64_t N, int nbits, int k, void *stream);
-int wv_merge_relbits_map(const uint64_t *relbits, const uint32_t *cum, int G, int Q, int kin, int k, int nbits, float *ap,
-                         int32_t *nrel, int32_t *need_out, void *stream);
+                             uint64_t *relbits, int64_t relbits_ld, uint32_t *cum, int64_t cum_ld, int Q, int64_t N, int nbits,
+                             int k, void *stream);
+int wv_merge_relbits_map(const uint64_t *relbits, int64_t relbits_ld, const uint32_t *cum, int64_t cum_ld, int G, int Q, int kin,
+                         int k, int nbits, float *ap, int32_t *nrel, int32_t *need_out, void *stream);
 
 /* Ranking from a stored distance matrix row (same order as wv_hamming_topk). */
 int wv_rank_from_dist(const uint8_t *dist_matrix, int64_t ld_dist, int Q, int64_t N, int nbits,

@@ -650,22 +650,16 @@ def test_sharded_map_from_relevance_strings_equals_unsharded(Q, N, nbits, k, G, 
     T = (cums.sum(0)[:, 1:] >= k).int().argmax(dim=1)
     need = int(torch.gather(cums, 2, (T + 1).view(1, Q, 1).expand(G, Q, 1).long()).max().item())
     for send, exact in ((min(min(k, per), need), True), (max(1, need - 1), need == 1)):
-        W = (send + 63) // 64
-        rbs, cs = [], []
+        wires = []
         for lo, hi, db, lab in shards:
-            rb = torch.zeros((Q, W), dtype=torch.int64, device="cuda")
-            c = torch.zeros((Q, nbits + 2), dtype=torch.int32, device="cuda")
+            wire = torch.zeros((Q, H.relbits_wire_words(send, nbits)), dtype=torch.int64, device="cuda")
             if db is not None:
-                w = min(send, hi - lo)
-                got = H.hamming_shard_relbits(qp, db, lab, qlp, nbits, w)
-                assert got is not None
-                rb[:, :got[0].shape[1]] = got[0]
-                c = got[1]
-            rbs.append(rb)
-            cs.append(c)
-        assert torch.equal(torch.stack(cs), cums)
+                assert H.hamming_shard_relbits(qp, db, lab, qlp, nbits, min(send, hi - lo), wire=wire, kin=send) is wire
+            wires.append(wire)
+        wires = torch.stack(wires)                                   # [G, Q, histogram | relevance string]
+        assert torch.equal(H.wire_histograms(wires, nbits), cums)
         owed = torch.zeros(1, dtype=torch.int32, device="cuda")
-        ap, nrel = H.merge_relbits_map(torch.stack(rbs), torch.stack(cs), send, k, nbits, need_out=owed)
+        ap, nrel = H.merge_relbits_map(wires, send, k, nbits, need_out=owed)
         assert int(owed.item()) == need and (need <= send) == exact
         if exact:
             assert torch.equal(nrel, nrel_ref) and torch.equal(ap, ap_ref)

@@ -73,24 +73,40 @@ def _label_words(rows):
     return (rows.long() << torch.arange(rows.shape[1])).sum(1, keepdim=True)
 
 
-def _fake_shard_relbits(q_packed, db, labels, qlab_packed, nbits, k):
-    """db: packed codes of the shard; labels: its label words [n, 1]; qlab_packed: label words of the queries [Q, 1]."""
+def _wire_words(kin, nbits):
+    return (nbits + 3) // 2 + (kin + 63) // 64
+
+
+def _fake_shard_relbits(q_packed, db, labels, qlab_packed, nbits, k, wire=None, kin=None):
+    """db: packed codes of the shard; labels: its label words [n, 1]; qlab_packed: label words of the queries [Q, 1].
+    Fills the wire rows [histogram as int32 pairs | relevance string] like the kernel does."""
     from oracle import ranking
+    kin = k if kin is None else kin
     idx, _ = ranking.hamming_topk_stable(_unpack(q_packed, nbits), _unpack(db, nbits), k)
     rel = (labels[:, 0][idx] & qlab_packed) != 0                              # [Q, k]
-    W = (k + 63) // 64
-    bits = torch.zeros((rel.shape[0], W * 64), dtype=torch.long)
+    Q, W, hw = rel.shape[0], (kin + 63) // 64, (nbits + 3) // 2
+    bits = torch.zeros((Q, W * 64), dtype=torch.long)
     bits[:, :k] = rel.long()
-    w = bits.reshape(-1, W, 64)
+    w = bits.reshape(Q, W, 64)
     sh = torch.arange(64)
     words = (w[..., :63] << sh[:63]).sum(-1) + torch.where(w[..., 63] > 0, torch.tensor(-2 ** 63), torch.tensor(0))
-    return words, _fake_hist(q_packed, db, nbits)
+    if wire is None:
+        wire = torch.zeros((Q, hw + W), dtype=torch.int64)
+    wire[:, hw:] = words
+    hist = torch.zeros((Q, 2 * hw), dtype=torch.int32)
+    hist[:, :nbits + 2] = _fake_hist(q_packed, db, nbits)
+    wire[:, :hw] = hist.view(torch.int64)
+    return wire
 
 
-def _fake_merge_relbits(relbits, cum, kin, k, nbits, need_out=None):
+def _fake_merge_relbits(wire, kin, k, nbits, need_out=None):
     """Expand every shard's string to one 0/1 entry per list position, merge by (distance, shard, position), AP as the
     reference computes it (fp32 quotients, mean over the hits)."""
-    G, Q, W = relbits.shape
+    G, Q, ld = wire.shape
+    hw = (nbits + 3) // 2
+    cum = wire[..., :hw].contiguous().view(torch.int32).reshape(G, Q, 2 * hw)[..., :nbits + 2].long()
+    relbits = wire[..., hw:]
+    W = relbits.shape[-1]
     if need_out is not None:
         T = (cum.sum(0)[:, 1:] >= k).int().argmax(dim=1)
         owed = torch.gather(cum, 2, (T + 1).view(1, Q, 1).expand(G, Q, 1).long()).max()
@@ -169,7 +185,7 @@ def _map_worker(rank, world, port, cases, nbits, ql, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from wvhash import parallel, synth
     from wvhash.engine import hamming as H
-    H.hamming_shard_relbits, H.merge_relbits_map = _fake_shard_relbits, _fake_merge_relbits
+    H.hamming_shard_relbits, H.merge_relbits_map, H.relbits_wire_words = _fake_shard_relbits, _fake_merge_relbits, _wire_words
     out = {}
     for n_db, k in cases:
         q_all, r = synth.random_codes(world * ql, n_db, nbits, seed=3)

@@ -35,14 +35,14 @@ for world in (1, 2, 4, 8):
     # mAP without lists: relevance strings + histograms from the shard, merge + AP on the receiving rank
     lab = H.PreparedLabels(H.pack_labels(synth.multi_hot_labels(per, 38, 0.1, 2).cuda()))
     qlab = H.pack_labels(synth.multi_hot_labels(world * QL, 38, 0.1, 1).cuda())
-    t_rel = timeit(lambda: H.hamming_shard_relbits(qp, prep, lab, qlab, 64, send))
-    rb, cm = H.hamming_shard_relbits(qp[:QL], prep, lab, qlab[:QL], 64, send)
-    rbs, cms = rb.unsqueeze(0).expand(world, -1, -1).contiguous(), cm.unsqueeze(0).expand(world, -1, -1).contiguous()
-    t_mrel = timeit(lambda: H.merge_relbits_map(rbs, cms, send, min(K, world * send), 64)) if world > 1 else 0.0
+    wbuf = torch.zeros((world * QL, H.relbits_wire_words(send, 64)), dtype=torch.int64, device="cuda")
+    t_rel = timeit(lambda: H.hamming_shard_relbits(qp, prep, lab, qlab, 64, send, wire=wbuf))
+    wires = H.hamming_shard_relbits(qp[:QL], prep, lab, qlab[:QL], 64, send).unsqueeze(0).expand(world, -1, -1).contiguous()
+    t_mrel = timeit(lambda: H.merge_relbits_map(wires, send, min(K, world * send), 64)) if world > 1 else 0.0
     mb = world * QL * (send * 2 + 66 * 4) / 1e6
     print(f"world={world}: one-step local rank of {world*QL} queries vs {per} rows (k'={kl}): {t_local*1e3:.0f} us | "
           f"two-step: histograms {t_hist*1e3:.0f} us + {send}-entry 16-bit lists {t_rows*1e3:.0f} us | "
           f"hinted one pass (lists + histograms): {t_one*1e3:.0f} us | "
           f"compact merge {world} x {send}: {t_merge*1e3:.0f} us | relevance strings {t_rel*1e3:.0f} us + merge/AP {t_mrel*1e3:.0f} us "
-          f"({world * QL * ((send + 63) // 64 * 8 + 66 * 4) / 1e6:.1f} MB sent) | lists: sent per rank ~{mb:.0f} MB "
+          f"({world * QL * H.relbits_wire_words(send, 64) * 8 / 1e6:.1f} MB sent, one all_to_all) | lists: sent per rank ~{mb:.0f} MB "
           f"(int32+u8 lists: {world * QL * send * 5 / 1e6:.0f} MB)", flush=True)
