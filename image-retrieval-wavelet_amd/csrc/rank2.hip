@@ -92,8 +92,9 @@ struct Rank2Lds {
 
 // average precision instead of (or beside) the list: all pointers NULL = off
 struct Rank2Ap {
-    const uint32_t *cls;     // class-major label bit matrix [64][ceil(N / 32)] (rank2_labels_prepare)
-    const uint64_t *qlab;    // [Q] label word of every query
+    const uint32_t *cls;     // class-major label bit matrix [64 * lwords][ceil(N / 32)] (rank2_labels_prepare)
+    const uint64_t *qlab;    // [Q][lwords] label words of every query
+    int lwords;              // 1 or 2 (up to 128 classes)
     float *ap;               // [Q]
     int32_t *nrel;           // [Q] relevant entries among the k (or NULL)
     uint64_t *relbits;       // [Q][ceil(k / 64)] instead of ap: the relevance string of the list (sharded mAP)
@@ -229,7 +230,8 @@ __device__ __forceinline__ void rank2_hist_only(const uint32_t (&dc)[NC], int64_
 // of the query's classes -- a few 3 KB rows instead of all N label words (a pass over N x 8 bytes per query, the size of
 // the code image, cost as much as the distance pass: the texture path moves 64 bytes per clock and CU).
 template <int TPQ>
-__device__ __forceinline__ void rank2_relevance_bitmap(const uint32_t *__restrict__ cls, uint64_t ql, int nw, int t, uint32_t *bitmap)
+__device__ __forceinline__ void rank2_relevance_bitmap(const uint32_t *__restrict__ cls, uint64_t ql, uint64_t ql_hi, int nw, int t,
+                                                       uint32_t *bitmap)
 {
     // A thread owns words t, t + TPQ, ... (at most 4: N <= 32768).  Per round four classes x four words = 16 loads are
     // issued before the first is used: an L2 round trip costs ~4 k cycles under this kernel's load, a word-by-word,
@@ -240,14 +242,16 @@ __device__ __forceinline__ void rank2_relevance_bitmap(const uint32_t *__restric
 #pragma unroll
     for (int i = 0; i < WPT; ++i) wi[i] = min(t + i * TPQ, nw - 1);
     uint64_t m = ql;                                             // uniform: the loop runs on the scalar unit
+    int cbase = 0;                                               // classes 0-63, then (two label words) 64-127
+    if (!m) { m = ql_hi; ql_hi = 0; cbase = 64; }
     while (m) {
-        const int c0 = __builtin_ctzll(m);
+        const int c0 = cbase + __builtin_ctzll(m);
         m &= m - 1;
-        const int c1 = m ? __builtin_ctzll(m) : c0;
+        const int c1 = m ? cbase + __builtin_ctzll(m) : c0;
         m &= m - 1;
-        const int c2 = m ? __builtin_ctzll(m) : c0;
+        const int c2 = m ? cbase + __builtin_ctzll(m) : c0;
         m &= m - 1;
-        const int c3 = m ? __builtin_ctzll(m) : c0;
+        const int c3 = m ? cbase + __builtin_ctzll(m) : c0;
         m &= m - 1;
         uint32_t v[4][WPT];
 #pragma unroll
@@ -259,6 +263,7 @@ __device__ __forceinline__ void rank2_relevance_bitmap(const uint32_t *__restric
         }
 #pragma unroll
         for (int i = 0; i < WPT; ++i) acc[i] |= (v[0][i] | v[1][i]) | (v[2][i] | v[3][i]);
+        if (!m && ql_hi) { m = ql_hi; ql_hi = 0; cbase = 64; }   // second label word
     }
 #pragma unroll
     for (int i = 0; i < WPT; ++i)
@@ -314,7 +319,7 @@ __device__ __forceinline__ void rank2_one_query(const uint32_t (&dc)[NC], uint32
                                                 int nbins, int k, int64_t idx_offset, int32_t *__restrict__ idx_out,
                                                 uint16_t *__restrict__ rows16_out, uint8_t *__restrict__ dist_out,
                                                 uint32_t *__restrict__ cum_out, uint8_t *lds_raw, int t,
-                                                const uint32_t *__restrict__ cls = nullptr, uint64_t qlabel = 0,
+                                                const uint32_t *__restrict__ cls = nullptr, uint64_t qlabel = 0, uint64_t qlabel_hi = 0,
                                                 float *__restrict__ ap_out = nullptr, int32_t *__restrict__ nrel_out = nullptr,
                                                 uint64_t *__restrict__ relbits_out = nullptr)
 {
@@ -330,7 +335,7 @@ __device__ __forceinline__ void rank2_one_query(const uint32_t (&dc)[NC], uint32
     L.misc = L.tot + kWinBins;
     uint32_t *bitmap = L.misc + 4;                               // relevance of every item (AP only)
     R2_STAMP_INIT;
-    if constexpr (AP) rank2_relevance_bitmap<TPQ>(cls, qlabel, rank2_bitmap_words(N), t, bitmap);
+    if constexpr (AP) rank2_relevance_bitmap<TPQ>(cls, qlabel, qlabel_hi, rank2_bitmap_words(N), t, bitmap);
     R2_STAMP(6);
     const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform
     constexpr int NW = TPQ / 64;                                 // waves per query
@@ -571,28 +576,30 @@ __global__ __launch_bounds__(256) void k_rank2_image(const uint64_t *__restrict_
     }
 }
 
-// Class-major label bit matrix: cls[c][w] bit j = row 32 w + j carries class c (bit c of its 64-bit label word).
-__global__ __launch_bounds__(256) void k_rank2_label_matrix(const uint64_t *__restrict__ dblab, uint32_t *__restrict__ cls, int64_t N, int nw)
+// Class-major label bit matrix: cls[c][w] bit j = row 32 w + j carries class c (bit c % 64 of its label word c / 64).
+__global__ __launch_bounds__(256) void k_rank2_label_matrix(const uint64_t *__restrict__ dblab, uint32_t *__restrict__ cls, int64_t N,
+                                                            int nw, int lwords)
 {
+    const int ncls = 64 * lwords;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one thread per (word, class), the class fastest
-    if (i >= (int64_t)nw * 64) return;
-    const int c = (int)(i & 63);
-    const int64_t w = i >> 6;
+    if (i >= (int64_t)nw * ncls) return;
+    const int c = (int)(i % ncls);
+    const int64_t w = i / ncls;
     uint32_t word = 0;
     for (int j = 0; j < 32; ++j) {
         const int64_t r = w * 32 + j;
-        if (r < N) word |= (uint32_t)((dblab[r] >> c) & 1ull) << j;
+        if (r < N) word |= (uint32_t)((dblab[r * lwords + (c >> 6)] >> (c & 63)) & 1ull) << j;
     }
     cls[(size_t)c * nw + w] = word;
 }
 
-size_t rank2_labels_bytes(int64_t N) { return (size_t)64 * rank2_bitmap_words(N) * sizeof(uint32_t); }
+size_t rank2_labels_bytes(int64_t N, int lwords) { return (size_t)64 * lwords * rank2_bitmap_words(N) * sizeof(uint32_t); }
 
-int rank2_labels_prepare(const uint64_t *dblab, void *cls, int64_t N, hipStream_t st)
+int rank2_labels_prepare(const uint64_t *dblab, void *cls, int64_t N, int lwords, hipStream_t st)
 {
     const int nw = rank2_bitmap_words(N);
-    hipLaunchKernelGGL(k_rank2_label_matrix, dim3((unsigned)ceil_div((int64_t)nw * 64, 256)), dim3(256), 0, st, dblab,
-                       (uint32_t *)cls, N, nw);
+    hipLaunchKernelGGL(k_rank2_label_matrix, dim3((unsigned)ceil_div((int64_t)nw * 64 * lwords, 256)), dim3(256), 0, st, dblab,
+                       (uint32_t *)cls, N, nw, lwords);
     WV_CHECK_LAUNCH("k_rank2_label_matrix");
     return WV_OK;
 }
@@ -634,13 +641,15 @@ __global__ __launch_bounds__(256, rank2_min_waves(NC, QB)) void k_rank_window(co
             rank2_hist_only<TPQ, NC>(dc[qq], N, C, nbins, cum + (int64_t)qi * (nbins + 1), lds, t);
         else if (qi < Q) {                                       // uniform over the group (and over the workgroup when TPQ = 256)
             if constexpr (AP) {
-                const uint64_t lw = apx.qlab[qi];
+                const uint64_t lw = apx.qlab[(int64_t)qi * apx.lwords], lw2 = apx.lwords > 1 ? apx.qlab[(int64_t)qi * apx.lwords + 1] : 0;
                 const uint64_t ql = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(lw >> 32)) << 32) |
                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)lw);
+                const uint64_t ql2 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(lw2 >> 32)) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)lw2);
                 rank2_one_query<TPQ, NC, true>(dc[qq], dmin[qq], N, C, nbins, k, idx_offset, idx ? idx + (int64_t)qi * k : nullptr,
                                                rows16 ? rows16 + (int64_t)qi * k : nullptr, dist ? dist + (int64_t)qi * k : nullptr,
                                                cum ? cum + (int64_t)qi * (apx.cum_ld ? apx.cum_ld : nbins + 1) : nullptr, lds, t,
-                                               apx.cls, ql, apx.ap ? apx.ap + qi : nullptr, apx.nrel ? apx.nrel + qi : nullptr,
+                                               apx.cls, ql, ql2, apx.ap ? apx.ap + qi : nullptr, apx.nrel ? apx.nrel + qi : nullptr,
                                                apx.relbits ? apx.relbits + (int64_t)qi * (apx.relbits_ld ? apx.relbits_ld : (k + 63) / 64)
                                                            : nullptr);
             } else {
@@ -738,12 +747,12 @@ static int launch_rank2_t(const uint64_t *q, const void *img, int32_t *idx, uint
 // idx (int32 global indices) or rows16 (16-bit local row numbers) receives the list; k == 0: histogram only
 int rank2_launch(const uint64_t *q, const void *img, int32_t *idx, uint16_t *rows16, uint8_t *dist, int Q, int64_t N, int nbits,
                  int k, int64_t idx_offset, uint32_t *cum, int tpq, hipStream_t st, const void *lab_img, const uint64_t *qlab,
-                 float *ap, int32_t *nrel, uint64_t *relbits, int64_t relbits_ld, int64_t cum_ld)
+                 float *ap, int32_t *nrel, uint64_t *relbits, int64_t relbits_ld, int64_t cum_ld, int lwords)
 {
     const int nbins = nbits + 1, words = (nbits + 63) / 64;
-    Rank2Ap apx{reinterpret_cast<const uint32_t *>(lab_img), qlab, ap, nrel, relbits, relbits_ld, cum_ld};
+    Rank2Ap apx{reinterpret_cast<const uint32_t *>(lab_img), qlab, lwords, ap, nrel, relbits, relbits_ld, cum_ld};
     if (ap || relbits) {
-        if (!lab_img || !qlab || k < 1 || k > kApRounds * tpq) return 1;                     // the AP walk keeps <= 32 positions per thread
+        if (!lab_img || !qlab || k < 1 || k > kApRounds * tpq || lwords < 1 || lwords > 2) return 1;                     // the AP walk keeps <= 32 positions per thread
         const size_t per_g = tpq == 64 ? 4 * rank2_lds_bytes_per_query<64>(k, rank2_bitmap_words(N))
                                        : rank2_lds_bytes_per_query<256>(k, rank2_bitmap_words(N));
         if (per_g > 100 * 1024) return 1;

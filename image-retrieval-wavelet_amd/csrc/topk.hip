@@ -26,13 +26,13 @@ constexpr int kTopkThreads = 256;
 int rank2_tpq(int Q, int64_t N, int k);
 size_t rank2_image_bytes(int64_t N, int words, int tpq);
 int rank2_prepare(const uint64_t *db, void *img, int64_t N, int words, int tpq, hipStream_t st);
-size_t rank2_labels_bytes(int64_t N);
-int rank2_labels_prepare(const uint64_t *dblab, void *cls, int64_t N, hipStream_t st);
+size_t rank2_labels_bytes(int64_t N, int lwords);
+int rank2_labels_prepare(const uint64_t *dblab, void *cls, int64_t N, int lwords, hipStream_t st);
 // lab_img (the class-major label bit matrix) / qlab / ap / nrel: average precision of the list (wv_hamming_map_at_k); all NULL otherwise
 int rank2_launch(const uint64_t *q, const void *img, int32_t *idx, uint16_t *rows16, uint8_t *dist, int Q, int64_t N, int nbits,
                  int k, int64_t idx_offset, uint32_t *cum, int tpq, hipStream_t st, const void *lab_img = nullptr,
                  const uint64_t *qlab = nullptr, float *ap = nullptr, int32_t *nrel = nullptr, uint64_t *relbits = nullptr,
-                 int64_t relbits_ld = 0, int64_t cum_ld = 0);
+                 int64_t relbits_ld = 0, int64_t cum_ld = 0, int lwords = 1);
 // the one-wave-per-query image exists for databases (shards) of at most this many rows
 constexpr int64_t kImg64MaxRows = 64 * 64;
 // images of the windowed kernel exist for databases it can take at all (16-bit item numbers, <= 128 items per thread)
@@ -1089,24 +1089,29 @@ extern "C" int wv_hamming_topk_ex(const uint64_t *q, const uint64_t *db, const v
 }
 
 // ---------------------------------------------------------------------------------- mAP without the lists
-extern "C" size_t wv_rank_labels_prepared_bytes(int64_t N)
+extern "C" size_t wv_rank_labels_prepared_bytes(int64_t N, int lwords)
 {
-    if (N < 1 || N > kImg256MaxRows) return 0;
-    return rank2_labels_bytes(N);
+    if (N < 1 || N > kImg256MaxRows || lwords < 1 || lwords > 2) return 0;
+    return rank2_labels_bytes(N, lwords);
 }
 
-extern "C" int wv_rank_labels_prepare(const uint64_t *dblab, int64_t N, void *prepared_labels, size_t prepared_bytes, void *stream)
+extern "C" int wv_rank_labels_prepare(const uint64_t *dblab, int64_t N, int lwords, void *prepared_labels, size_t prepared_bytes,
+                                      void *stream)
 {
     WV_REQUIRE(dblab && prepared_labels, "rank_labels_prepare: null buffer");
-    const size_t need = wv_rank_labels_prepared_bytes(N);
-    if (!need) WV_FAIL(WV_ENOTSUP, "rank_labels_prepare: %lld rows are outside the windowed ranking kernel (<= 32768)", (long long)N);
+    const size_t need = wv_rank_labels_prepared_bytes(N, lwords);
+    if (!need)
+        WV_FAIL(WV_ENOTSUP, "rank_labels_prepare: %lld rows x %d label words are outside the fused kernels (<= 32768 rows, <= 128 classes)",
+                (long long)N, lwords);
     if (prepared_bytes < need) WV_FAIL(WV_ENOMEM, "rank_labels_prepare: buffer %zu < %zu bytes", prepared_bytes, need);
-    return rank2_labels_prepare(dblab, prepared_labels, N, (hipStream_t)stream);
+    return rank2_labels_prepare(dblab, prepared_labels, N, lwords, (hipStream_t)stream);
 }
 
 extern "C" int wv_hamming_map_at_k(const uint64_t *q, const void *prepared, const void *prepared_labels, const uint64_t *qlab,
-                                   int Q, int64_t N, int nbits, int k, float *ap, int32_t *nrel, void *stream)
+                                   int lwords, int Q, int64_t N, int nbits, int k, float *ap, int32_t *nrel, void *stream)
 {
+    WV_REQUIRE(lwords >= 1, "hamming_map_at_k: lwords=%d", lwords);
+    if (lwords > 2) WV_FAIL(WV_ENOTSUP, "hamming_map_at_k: %d label words (more than 128 classes): wv_hamming_topk + wv_map_at_k", lwords);
     WV_REQUIRE(q && prepared && prepared_labels && qlab && ap, "hamming_map_at_k: null buffer");
     WV_REQUIRE(Q >= 0 && N >= 1, "hamming_map_at_k: bad shape Q=%d N=%lld", Q, (long long)N);
     WV_REQUIRE(nbits >= 1 && nbits <= 128, "hamming_map_at_k: nbits=%d (supported: 1..128)", nbits);
@@ -1121,7 +1126,7 @@ extern "C" int wv_hamming_map_at_k(const uint64_t *q, const void *prepared, cons
     const char *base = (const char *)prepared + align_up((int64_t)dist_prepared_bytes(N, words), 256);
     const void *img = base + (tpq == 256 ? r2_off256(N, words) : r2_off64(N, words));
     const int rc = rank2_launch(q, img, nullptr, nullptr, nullptr, Q, N, nbits, k, 0, nullptr, tpq, (hipStream_t)stream,
-                                prepared_labels, qlab, ap, nrel);
+                                prepared_labels, qlab, ap, nrel, nullptr, 0, 0, lwords);
     if (rc > 0) WV_FAIL(WV_ENOTSUP, "hamming_map_at_k: k=%d is outside the fused kernel (wv_hamming_topk + wv_map_at_k)", k);
     return rc;
 }
@@ -1173,9 +1178,11 @@ extern "C" int wv_hamming_shard_prefix(const uint64_t *q, const uint64_t *db, co
 }
 
 extern "C" int wv_hamming_shard_relbits(const uint64_t *q, const void *prepared, const void *prepared_labels, const uint64_t *qlab,
-                                        uint64_t *relbits, int64_t relbits_ld, uint32_t *cum, int64_t cum_ld, int Q, int64_t N,
-                                        int nbits, int k, void *stream)
+                                        int lwords, uint64_t *relbits, int64_t relbits_ld, uint32_t *cum, int64_t cum_ld, int Q,
+                                        int64_t N, int nbits, int k, void *stream)
 {
+    WV_REQUIRE(lwords >= 1, "hamming_shard_relbits: lwords=%d", lwords);
+    if (lwords > 2) WV_FAIL(WV_ENOTSUP, "hamming_shard_relbits: %d label words (more than 128 classes)", lwords);
     WV_REQUIRE((relbits_ld == 0 || relbits_ld >= (k + 63) / 64) && (cum_ld == 0 || cum_ld >= nbits + 2),
                "hamming_shard_relbits: row pitches %lld / %lld too small", (long long)relbits_ld, (long long)cum_ld);
     WV_REQUIRE(q && prepared && prepared_labels && qlab && relbits && cum, "hamming_shard_relbits: null buffer");
@@ -1191,7 +1198,7 @@ extern "C" int wv_hamming_shard_relbits(const uint64_t *q, const void *prepared,
     const char *base = (const char *)prepared + align_up((int64_t)dist_prepared_bytes(N, words), 256);
     const void *img = base + (tpq == 256 ? r2_off256(N, words) : r2_off64(N, words));
     const int rc = rank2_launch(q, img, nullptr, nullptr, nullptr, Q, N, nbits, k, 0, cum, tpq, (hipStream_t)stream, prepared_labels,
-                                qlab, nullptr, nullptr, relbits, relbits_ld, cum_ld);
+                                qlab, nullptr, nullptr, relbits, relbits_ld, cum_ld, lwords);
     if (rc > 0) WV_FAIL(WV_ENOTSUP, "hamming_shard_relbits: k=%d is outside the fused kernel", k);
     return rc;
 }

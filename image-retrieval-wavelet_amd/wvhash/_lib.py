@@ -72,12 +72,12 @@ SIGNATURES = {
     "wv_hamming_dist_prepared": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _i, _vp]),
     "wv_hamming_topk_prepared": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i64, _vp]),
     "wv_hamming_topk_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i64, _vp, _sz, _vp]),
-    "wv_rank_labels_prepared_bytes": (_sz, [ctypes.c_int64]),
-    "wv_rank_labels_prepare": (_i, [_vp, ctypes.c_int64, _vp, _sz, _vp]),
-    "wv_hamming_map_at_k": (_i, [_vp, _vp, _vp, _vp, _i, ctypes.c_int64, _i, _i, _vp, _vp, _vp]),
+    "wv_rank_labels_prepared_bytes": (_sz, [ctypes.c_int64, _i]),
+    "wv_rank_labels_prepare": (_i, [_vp, ctypes.c_int64, _i, _vp, _sz, _vp]),
+    "wv_hamming_map_at_k": (_i, [_vp, _vp, _vp, _vp, _i, _i, ctypes.c_int64, _i, _i, _vp, _vp, _vp]),
     "wv_hamming_hist": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _sz, _vp]),
     "wv_hamming_topk_rows16": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _sz, _vp]),
-    "wv_hamming_shard_relbits": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i64, _i, _i, _vp]),
+    "wv_hamming_shard_relbits": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i64, _vp, _i64, _i, _i64, _i, _i, _vp]),
     "wv_merge_relbits_map": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "wv_hamming_shard_prefix": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _sz, _vp]),
     "wv_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp]),

@@ -218,7 +218,7 @@ class CustomCalculator(object):
             # (same numbers as the two steps below; None = shape outside the fused kernel)
             qlp, rlp = self._packed_labels(query_labels, reference_labels)
             fused = H.hamming_map_at_k(H.pack_codes(query), H.PreparedDB(H.pack_codes(reference), reference.shape[1]),
-                                       H.PreparedLabels(rlp), qlp, reference.shape[1], topk) if rlp.shape[1] == 1 else None
+                                       H.PreparedLabels(rlp), qlp, reference.shape[1], topk) if rlp.shape[1] <= 2 else None
             if fused is not None:
                 ap = fused[0]
         if ap is None:

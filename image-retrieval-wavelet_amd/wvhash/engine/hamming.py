@@ -320,7 +320,7 @@ def map_at_k(idx, qlab_packed, dblab_packed, k=None):
 
 class PreparedLabels:
     """The database rows' packed label words laid out for the fused ranking + AP kernel (wv_rank_labels_prepare): one
-    64-bit multi-hot word per row, databases of at most 32,768 rows.  `ok` is False for anything else -- the caller then
+    or two 64-bit multi-hot words per row (up to 128 classes), databases of at most 32,768 rows.  `ok` is False for anything else -- the caller then
     ranks and evaluates in two steps."""
 
     def __init__(self, dblab_packed):
@@ -329,13 +329,13 @@ class PreparedLabels:
             raise ValueError("PreparedLabels: expected packed int64 label words [N, words] (see pack_codes)")
         self.packed = dblab_packed.contiguous()
         self.N, self.words = self.packed.shape
-        nbytes = lib.wv_rank_labels_prepared_bytes(self.N) if self.words == 1 and self.N else 0
+        nbytes = lib.wv_rank_labels_prepared_bytes(self.N, self.words) if self.words <= 2 and self.N else 0
         self.ok = nbytes > 0
         self.blob = None
         if self.ok:
             self.blob = torch.empty(nbytes, dtype=torch.uint8, device=self.packed.device)
             with torch.cuda.device(self.packed.device):
-                rc = lib.wv_rank_labels_prepare(_lib.ptr(self.packed), self.N, _lib.ptr(self.blob), ctypes.c_size_t(nbytes),
+                rc = lib.wv_rank_labels_prepare(_lib.ptr(self.packed), self.N, self.words, _lib.ptr(self.blob), ctypes.c_size_t(nbytes),
                                                 _lib.stream_ptr())
                 _lib.check(rc, "wv_rank_labels_prepare")
 
@@ -343,21 +343,21 @@ class PreparedLabels:
 def hamming_map_at_k(q_packed, db, labels, qlab_packed, nbits, k):
     """mAP@k ingredients straight from the codes -> (ap float32 [Q], nrel int32 [Q]), or None when the shape is outside
     the fused kernel (the caller then runs hamming_topk + map_at_k, which return exactly the same numbers).
-    db: PreparedDB; labels: PreparedLabels of the same rows; qlab_packed: int64 [Q, 1]."""
+    db: PreparedDB; labels: PreparedLabels of the same rows; qlab_packed: int64 [Q, 1 or 2]."""
     lib = _lib.require_gpu()
     if not isinstance(db, PreparedDB) or not isinstance(labels, PreparedLabels):
         raise TypeError("hamming_map_at_k: needs a PreparedDB and PreparedLabels")
     Q, words = q_packed.shape
     if words != db.words or labels.N != db.N:
         raise ValueError("hamming_map_at_k: query / database / label shapes disagree")
-    if not labels.ok or qlab_packed.shape[1] != 1 or nbits > 128 or not 1 <= k <= db.N:
+    if not labels.ok or qlab_packed.shape[1] != labels.words or nbits > 128 or not 1 <= k <= db.N:
         return None
     ap = torch.empty(Q, dtype=torch.float32, device=q_packed.device)
     nrel = torch.empty(Q, dtype=torch.int32, device=q_packed.device)
     if Q:
         with torch.cuda.device(q_packed.device):
             rc = lib.wv_hamming_map_at_k(_lib.ptr(q_packed.contiguous()), _lib.ptr(db.blob), _lib.ptr(labels.blob),
-                                         _lib.ptr(qlab_packed.contiguous()), Q, db.N, nbits, k, _lib.ptr(ap), _lib.ptr(nrel),
+                                         _lib.ptr(qlab_packed.contiguous()), labels.words, Q, db.N, nbits, k, _lib.ptr(ap), _lib.ptr(nrel),
                                          _lib.stream_ptr())
             if rc == -95:      # WV_ENOTSUP
                 return None
@@ -383,7 +383,7 @@ def hamming_shard_relbits(q_packed, db, labels, qlab_packed, nbits, k, wire=None
     Q, words = q_packed.shape
     if words != db.words or labels.N != db.N:
         raise ValueError("hamming_shard_relbits: query / database / label shapes disagree")
-    if not labels.ok or qlab_packed.shape[1] != 1 or nbits > 128 or not 1 <= k <= db.N:
+    if not labels.ok or qlab_packed.shape[1] != labels.words or nbits > 128 or not 1 <= k <= db.N:
         return None
     kin = k if kin is None else kin
     dev = q_packed.device
@@ -396,7 +396,7 @@ def hamming_shard_relbits(q_packed, db, labels, qlab_packed, nbits, k, wire=None
         hist_words = (nbits + 3) // 2
         with torch.cuda.device(dev):
             rc = lib.wv_hamming_shard_relbits(_lib.ptr(q_packed.contiguous()), _lib.ptr(db.blob), _lib.ptr(labels.blob),
-                                              _lib.ptr(qlab_packed.contiguous()), wire.data_ptr() + 8 * hist_words, ld,
+                                              _lib.ptr(qlab_packed.contiguous()), labels.words, wire.data_ptr() + 8 * hist_words, ld,
                                               wire.data_ptr(), 2 * ld, Q, db.N, nbits, k, _lib.stream_ptr())
             if rc == -95:      # WV_ENOTSUP
                 return None

@@ -204,7 +204,7 @@ def sharded_hamming_map_at_k(q_local, qlab_local, db_shard, labels_shard, nbits,
     merged string exactly as map_at_k evaluates a list.  Per step: one all_gather, one ranking pass per shard, ONE small
     all_to_all (histogram and string side by side: 264 + 136 bytes per query and shard at 8 GPUs instead of 264 + 2,128 in
     two), one merge kernel.
-    q_local int64 [Ql, words]; qlab_local int64 [Ql, 1]; db_shard PreparedDB and labels_shard PreparedLabels of this rank's
+    q_local int64 [Ql, words]; qlab_local int64 [Ql, 1 or 2] (up to 128 classes); db_shard PreparedDB and labels_shard PreparedLabels of this rank's
     rows; send_hint: the prefix length (as for sharded_hamming_topk: learn it from an exactly-sized list step, check the
     returned `need` with exchange_ok)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -215,7 +215,7 @@ def sharded_hamming_map_at_k(q_local, qlab_local, db_shard, labels_shard, nbits,
     Ql, words = q_local.shape
     lo, hi, per = shard_bounds(n_total, world, rank)
     n_local = hi - lo
-    if per > H.SHARD_ROWS_MAX or k > 8192 or qlab_local.shape[1] != 1 or nbits > 128 or send_hint is None:
+    if per > H.SHARD_ROWS_MAX or k > 8192 or qlab_local.shape[1] > 2 or nbits > 128 or send_hint is None:
         return None                                      # decided from values every rank shares: no rank goes another way
     dev = q_local.device
     both = torch.cat([q_local, qlab_local], dim=1).contiguous()           # codes | label word: one collective

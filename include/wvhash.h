@@ -182,17 +182,17 @@ int wv_hamming_topk_ex(const uint64_t *q, const uint64_t *db, const void *prepar
 /* mAP@k of every query straight from the codes -- what calculate_maphashing (accuracy_calculator.py:183-231) returns -- without
  * writing the ranked lists: the windowed ranking kernel builds the list in LDS as wv_hamming_topk does (ascending distance,
  * ties by ascending row) and evaluates it there against a relevance bitmap of the query made from the rows' label words
- * (one 64-bit multi-hot word per row: label_comparison_fn, :31-37).  ap float32 [Q] and nrel int32 [Q] (or NULL) are exactly
+ * (lwords = 1 or 2 64-bit multi-hot words per row, i.e. up to 128 classes: label_comparison_fn, :31-37).  ap float32 [Q] and nrel int32 [Q] (or NULL) are exactly
  * what wv_map_at_k returns for wv_hamming_topk's list (same summation order; bit-identical at 256 threads per query).
  *   prepared         wv_db_prepare's blob of the database codes
  *   prepared_labels  wv_rank_labels_prepare's class-major bit matrix of the rows' label words
  *                    (wv_rank_labels_prepared_bytes(N) bytes; 0 = N is outside the windowed kernel)
  * Returns WV_ENOTSUP for shapes outside the fused kernel (more than 32,768 rows, k > 8,192, ...): the caller then runs
  * wv_hamming_topk + wv_map_at_k. */
-size_t wv_rank_labels_prepared_bytes(int64_t N);
-int wv_rank_labels_prepare(const uint64_t *dblab, int64_t N, void *prepared_labels, size_t prepared_bytes, void *stream);
-int wv_hamming_map_at_k(const uint64_t *q, const void *prepared, const void *prepared_labels, const uint64_t *qlab, int Q,
-                        int64_t N, int nbits, int k, float *ap, int32_t *nrel, void *stream);
+size_t wv_rank_labels_prepared_bytes(int64_t N, int lwords);
+int wv_rank_labels_prepare(const uint64_t *dblab, int64_t N, int lwords, void *prepared_labels, size_t prepared_bytes, void *stream);
+int wv_hamming_map_at_k(const uint64_t *q, const void *prepared, const void *prepared_labels, const uint64_t *qlab, int lwords,
+                        int Q, int64_t N, int nbits, int k, float *ap, int32_t *nrel, void *stream);
 
 /* The two steps of a row-sharded search (wvhash/parallel.py; the role of faiss' shard search + host merge at
  * get_knn.py:41-44) on one shard of at most 32,768 rows:
@@ -249,8 +249,8 @@ int wv_topk_merge_cum_need(const uint16_t *idx_local, const uint32_t *cum, int G
  * by side in ONE wire buffer, so that a single all_to_all moves both.
  * WV_ENOTSUP outside the windowed kernel's range (shards of more than 32,768 rows, k > 8,192, wider labels). */
 int wv_hamming_shard_relbits(const uint64_t *q, const void *prepared, const void *prepared_labels, const uint64_t *qlab,
-                             uint64_t *relbits, int64_t relbits_ld, uint32_t *cum, int64_t cum_ld, int Q, int64_t N, int nbits,
-                             int k, void *stream);
+                             int lwords, uint64_t *relbits, int64_t relbits_ld, uint32_t *cum, int64_t cum_ld, int Q, int64_t N,
+                             int nbits, int k, void *stream);
 int wv_merge_relbits_map(const uint64_t *relbits, int64_t relbits_ld, const uint32_t *cum, int64_t cum_ld, int G, int Q, int kin,
                          int k, int nbits, float *ap, int32_t *nrel, int32_t *need_out, void *stream);
 

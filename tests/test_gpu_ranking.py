@@ -578,7 +578,8 @@ def test_ap_of_list_prefixes_equals_ap_of_shorter_lists(Q, N, k, Lc):
 @pytest.mark.parametrize("Q,N,nbits,k,Lc,spread", [(2048, 25000, 64, 5000, 38, False), (37, 3000, 64, 2500, 24, True),
                                                    (5, 3000, 128, 3000, 64, True), (33, 1000, 64, 37, 5, True),
                                                    (6, 257, 32, 257, 1, True), (4100, 700, 64, 200, 38, False),
-                                                   (11, 32768, 64, 8192, 38, False), (3, 4096, 16, 2048, 10, False)])
+                                                   (11, 32768, 64, 8192, 38, False), (3, 4096, 16, 2048, 10, False),
+                                                   (41, 14653, 128, 5000, 80, False), (9, 2000, 64, 700, 128, False)])
 def test_fused_map_at_k_equals_ranking_then_ap(monkeypatch, variant, Q, N, nbits, k, Lc, spread):
     """wv_hamming_map_at_k (list built and evaluated in LDS, never written) against wv_hamming_topk + wv_map_at_k: AP and
     hit counts of every query.  256 threads per query use the AP kernel's summation order -- bit-identical; one wave per
@@ -619,15 +620,16 @@ def test_fused_map_at_k_equals_ranking_then_ap(monkeypatch, variant, Q, N, nbits
 def test_fused_map_at_k_refuses_what_it_cannot_do():
     q, r = synth.random_codes(4, 300, 64, seed=1)
     qp, prep = H.pack_codes(q.cuda()), H.PreparedDB(H.pack_codes(r.cuda()), 64)
-    wide = H.PreparedLabels(H.pack_labels(synth.multi_hot_labels(300, 100, 0.1, 1).cuda()))      # two label words per row
+    wide = H.PreparedLabels(H.pack_labels(synth.multi_hot_labels(300, 130, 0.1, 1).cuda()))      # three label words per row
     assert not wide.ok
-    assert H.hamming_map_at_k(qp, prep, wide, H.pack_labels(synth.multi_hot_labels(4, 100, 0.1, 2).cuda()), 64, 10) is None
+    assert H.hamming_map_at_k(qp, prep, wide, H.pack_labels(synth.multi_hot_labels(4, 130, 0.1, 2).cuda()), 64, 10) is None
     big = H.PreparedLabels(torch.zeros((40000, 1), dtype=torch.int64, device="cuda"))               # more rows than the kernel takes
     assert not big.ok
 
 
 @pytest.mark.parametrize("Q,N,nbits,k,G,Lc", [(37, 11000, 64, 3000, 8, 38), (19, 999, 16, 999, 3, 10), (4100, 5000, 64, 1200, 8, 38),
-                                              (21, 20000, 128, 5000, 7, 64), (9, 40, 32, 7, 5, 3), (64, 25000, 64, 5000, 8, 38)])
+                                              (21, 20000, 128, 5000, 7, 64), (9, 40, 32, 7, 5, 3), (64, 25000, 64, 5000, 8, 38),
+                                              (33, 117218, 128, 5000, 8, 80)])
 def test_sharded_map_from_relevance_strings_equals_unsharded(Q, N, nbits, k, G, Lc):
     """What the ranks of sharded_hamming_map_at_k run, for G shards on one GPU: wv_hamming_shard_relbits per shard (relevance
     string of the prefix + histograms) -> wv_merge_relbits_map.  AP and hit counts must equal map_at_k of the unsharded
