@@ -9,8 +9,12 @@
 // on the matrix cores with v_mfma_f32_32x32x2_f32 -- fp32 in, fp32 accumulate, bit-for-bit an
 // fmaf chain -- so the result stays within fp32 rounding of the reference's fp32 ATen path
 // instead of trading precision for bf16 MFMA rate.  The 4-token softmax / context step is a small
-// VALU kernel (QK^T is Nq x 4 per head).  The batch-invariant query projection is done once per
-// call.  Stages are separate launches writing to a caller workspace.
+// VALU kernel (QK^T is Nq x 4 per head).  This file holds the general path -- one launch per stage,
+// intermediates in a caller workspace -- for any shape, plus the read-out product, LayerNorm 2 and the
+// hashing tail every configuration uses.  For the shapes the reference runs (E = 384, 4 band tokens,
+// 4 or 8 queries) and batches that fill the chip, everything before the read-out is ONE kernel
+// (head_front.hip) fed by a weight stream wv_band_attn_prepare makes once per parameter update; the
+// batch-invariant query projection is likewise made once (wv_band_attn_qproj) and cached by the module.
 #include "common.hpp"
 
 namespace wv {
