@@ -180,7 +180,10 @@ class CustomCalculator(object):
         if self.rank_cache is not None:
             return self.rank_cache.lists(query, reference, topk)
         nbits = reference.shape[1]
-        return H.hamming_topk(H.pack_codes(query), H.pack_codes(reference), nbits, topk, want_dist=False)[0]
+        rp = H.pack_codes(reference)
+        if rp.shape[0] > H.SHARD_ROWS_MAX:               # large database: virtual shards through the windowed kernel
+            rp = H.PreparedDB(rp, nbits)
+        return H.hamming_topk(H.pack_codes(query), rp, nbits, topk, want_dist=False)[0]
 
     @staticmethod
     def _packed_labels(query_labels, reference_labels):

@@ -65,11 +65,14 @@ def bit_counts(packed, nbits):
     return counts
 
 
+SHARD_ROWS_MAX = 32768      # wv_hamming_hist / wv_hamming_topk_rows16 take shards up to this many rows
+
+
 class PreparedDB:
     """A packed database laid out once for the kernels (wv_db_prepare): what index.add() is to the
     reference's faiss path (get_knn.py:54), except that it is built once per database, not per call."""
 
-    def __init__(self, db_packed, nbits=None):
+    def __init__(self, db_packed, nbits=None, _virtual=True):
         lib = _lib.require_gpu()
         if db_packed.dim() != 2 or db_packed.dtype != torch.int64:
             raise ValueError("PreparedDB: expected packed int64 codes [N, words] (see pack_codes)")
@@ -83,6 +86,16 @@ class PreparedDB:
                 rc = lib.wv_db_prepare(_lib.ptr(self.packed), self.N, self.words, _lib.ptr(self.blob),
                                        ctypes.c_size_t(nbytes), _lib.stream_ptr())
                 _lib.check(rc, "wv_db_prepare")
+        # A database beyond the windowed ranking kernel's 32,768 rows is ranked as contiguous VIRTUAL shards on the one
+        # GPU (the row-sharded search of wvhash/parallel.py without the collectives: histograms -> prefix length ->
+        # 16-bit list prefixes -> merge): 117,218 x 128-bit codes, 5000 queries, k = 5000: 1.1 ms instead of 1.83 ms for
+        # the first-generation kernel.
+        self.parts, self.per = None, None
+        if SHARD_ROWS_MAX < self.N <= 64 * SHARD_ROWS_MAX and self.words <= 2 and _virtual:
+            g = -(-self.N // SHARD_ROWS_MAX)
+            self.per = -(-self.N // g)
+            self.parts = [PreparedDB(self.packed[lo:min(self.N, lo + self.per)], self.nbits, _virtual=False)
+                          for lo in range(0, self.N, self.per)]
 
     @property
     def shape(self):
@@ -147,6 +160,8 @@ def hamming_topk(q_packed, db, nbits, k, idx_offset=0, workspace=None, want_dist
     if dwords != words or words != _words(nbits):
         raise ValueError("hamming_topk: code widths do not match nbits")
     dev = q_packed.device
+    if prepared and db.parts and not want_cum and nbits <= 128 and Q:
+        return _virtual_shards_topk(q_packed, db, nbits, k, idx_offset, want_dist)
     idx = torch.empty((Q, k), dtype=torch.int32, device=dev)
     dist = torch.empty((Q, k), dtype=torch.uint8, device=dev) if want_dist else None
     if want_cum:
@@ -179,15 +194,34 @@ def hamming_topk(q_packed, db, nbits, k, idx_offset=0, workspace=None, want_dist
     return idx, dist
 
 
+def _prefix_need(cums, k):
+    """cums int32 [G, Q, nbits + 2] -> the longest list prefix any shard owes any query (host int): local rows with
+    distance <= T, T = the query's global k-th distance."""
+    G, Q, _ = cums.shape
+    T = (cums.sum(0)[:, 1:] >= k).int().argmax(dim=1)
+    return int(torch.gather(cums, 2, (T + 1).view(1, Q, 1).expand(G, Q, 1).long()).max().item())
+
+
+def _virtual_shards_topk(q_packed, db, nbits, k, idx_offset, want_dist):
+    cums = torch.stack([hamming_hist(q_packed, part, nbits) for part in db.parts])
+    send = max(1, min(k, db.per, _prefix_need(cums, k)))        # one host read, as in the un-hinted sharded search
+    Q = q_packed.shape[0]
+    lists = torch.zeros((len(db.parts), Q, send), dtype=torch.int16, device=q_packed.device)
+    for g, part in enumerate(db.parts):
+        w = min(send, part.N)
+        lists[g, :, :w] = hamming_topk_rows16(q_packed, part, nbits, w)
+    idx, dist = topk_merge_cum(lists, cums, db.per, k, nbits)
+    if idx_offset:
+        idx += int(idx_offset)
+    return idx, (dist if want_dist else None)
+
+
 def _shard_db_args(db, words, nbits, what):
     prepared = isinstance(db, PreparedDB)
     N, dwords = (db.N, db.words) if prepared else db.shape
     if dwords != words or words != _words(nbits):
         raise ValueError(f"{what}: code widths do not match nbits")
     return prepared, N
-
-
-SHARD_ROWS_MAX = 32768      # wv_hamming_hist / wv_hamming_topk_rows16 take shards up to this many rows
 
 
 def hamming_hist(q_packed, db, nbits, workspace=None):
@@ -323,16 +357,21 @@ class PreparedLabels:
     or two 64-bit multi-hot words per row (up to 128 classes), databases of at most 32,768 rows.  `ok` is False for anything else -- the caller then
     ranks and evaluates in two steps."""
 
-    def __init__(self, dblab_packed):
+    def __init__(self, dblab_packed, _virtual=True):
         lib = _lib.require_gpu()
         if dblab_packed.dim() != 2 or dblab_packed.dtype != torch.int64:
             raise ValueError("PreparedLabels: expected packed int64 label words [N, words] (see pack_codes)")
         self.packed = dblab_packed.contiguous()
         self.N, self.words = self.packed.shape
-        nbytes = lib.wv_rank_labels_prepared_bytes(self.N, self.words) if self.words <= 2 and self.N else 0
-        self.ok = nbytes > 0
+        self.parts = None
+        if SHARD_ROWS_MAX < self.N <= 64 * SHARD_ROWS_MAX and self.words <= 2 and _virtual:      # as PreparedDB: virtual shards
+            g = -(-self.N // SHARD_ROWS_MAX)
+            per = -(-self.N // g)
+            self.parts = [PreparedLabels(self.packed[lo:min(self.N, lo + per)], _virtual=False) for lo in range(0, self.N, per)]
+        nbytes = lib.wv_rank_labels_prepared_bytes(self.N, self.words) if self.words <= 2 and self.N and not self.parts else 0
+        self.ok = nbytes > 0 or bool(self.parts)
         self.blob = None
-        if self.ok:
+        if nbytes:
             self.blob = torch.empty(nbytes, dtype=torch.uint8, device=self.packed.device)
             with torch.cuda.device(self.packed.device):
                 rc = lib.wv_rank_labels_prepare(_lib.ptr(self.packed), self.N, self.words, _lib.ptr(self.blob), ctypes.c_size_t(nbytes),
@@ -352,6 +391,16 @@ def hamming_map_at_k(q_packed, db, labels, qlab_packed, nbits, k):
         raise ValueError("hamming_map_at_k: query / database / label shapes disagree")
     if not labels.ok or qlab_packed.shape[1] != labels.words or nbits > 128 or not 1 <= k <= db.N:
         return None
+    if db.parts or labels.parts:                         # more than 32,768 rows: virtual shards, relevance strings, one merge
+        if not (db.parts and labels.parts) or len(db.parts) != len(labels.parts) or k > 8192 or not Q:
+            return None
+        cums = torch.stack([hamming_hist(q_packed, part, nbits) for part in db.parts])
+        send = max(1, min(k, db.per, _prefix_need(cums, k)))
+        wires = torch.zeros((len(db.parts), Q, relbits_wire_words(send, nbits)), dtype=torch.int64, device=q_packed.device)
+        for g, (part, lab) in enumerate(zip(db.parts, labels.parts)):
+            if hamming_shard_relbits(q_packed, part, lab, qlab_packed, nbits, min(send, part.N), wire=wires[g], kin=send) is None:
+                return None
+        return merge_relbits_map(wires, send, k, nbits)
     ap = torch.empty(Q, dtype=torch.float32, device=q_packed.device)
     nrel = torch.empty(Q, dtype=torch.int32, device=q_packed.device)
     if Q:

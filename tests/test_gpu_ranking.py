@@ -623,8 +623,10 @@ def test_fused_map_at_k_refuses_what_it_cannot_do():
     wide = H.PreparedLabels(H.pack_labels(synth.multi_hot_labels(300, 130, 0.1, 1).cuda()))      # three label words per row
     assert not wide.ok
     assert H.hamming_map_at_k(qp, prep, wide, H.pack_labels(synth.multi_hot_labels(4, 130, 0.1, 2).cuda()), 64, 10) is None
-    big = H.PreparedLabels(torch.zeros((40000, 1), dtype=torch.int64, device="cuda"))               # more rows than the kernel takes
-    assert not big.ok
+    big = H.PreparedLabels(torch.zeros((40000, 1), dtype=torch.int64, device="cuda"))               # beyond one kernel launch:
+    assert big.ok and len(big.parts) == 2                                                           # two virtual shards
+    huge = H.PreparedLabels(torch.zeros((64 * 32768 + 1, 1), dtype=torch.int64, device="cuda"))     # beyond 64 virtual shards
+    assert not huge.ok
 
 
 @pytest.mark.parametrize("Q,N,nbits,k,G,Lc", [(37, 11000, 64, 3000, 8, 38), (19, 999, 16, 999, 3, 10), (4100, 5000, 64, 1200, 8, 38),
@@ -665,3 +667,27 @@ def test_sharded_map_from_relevance_strings_equals_unsharded(Q, N, nbits, k, G, 
         assert int(owed.item()) == need and (need <= send) == exact
         if exact:
             assert torch.equal(nrel, nrel_ref) and torch.equal(ap, ap_ref)
+
+
+@pytest.mark.parametrize("Q,N,nbits,k,Lc", [(33, 117218, 128, 5000, 80), (7, 40000, 64, 3000, 38), (5, 70001, 32, 8000, 5)])
+def test_databases_beyond_32768_rows_take_virtual_shards(Q, N, nbits, k, Lc):
+    """A PreparedDB of more than 32,768 rows is ranked as contiguous virtual shards through the windowed kernel (histograms
+    -> prefix length -> 16-bit lists -> merge): lists and distances identical to the first-generation kernel on the whole
+    database; wv_hamming_map_at_k's counterpart (relevance strings of the virtual shards) identical to ranking + AP."""
+    ql, rl = synth.multi_hot_labels(Q, Lc, 0.1, 31), synth.multi_hot_labels(N, Lc, 0.1, 32)
+    q, r = synth.structured_codes(ql, nbits, 3, 4), synth.structured_codes(rl, nbits, 3, 5)
+    qp, rp = H.pack_codes(q.cuda()), H.pack_codes(r.cuda())
+    prep = H.PreparedDB(rp, nbits)
+    assert prep.parts and len(prep.parts) == -(-N // 32768) and sum(p_.N for p_ in prep.parts) == N
+    idx0, d0 = H.hamming_topk(qp, rp, nbits, k)                   # raw tensor: first-generation kernel
+    idx1, d1 = H.hamming_topk(qp, prep, nbits, k, idx_offset=7)
+    assert torch.equal(idx1 - 7, idx0) and torch.equal(d1, d0)
+    ref_idx, ref_d = ranking.hamming_topk_stable(q[:4], r, k)
+    assert torch.equal(idx1[:4].cpu().long() - 7, ref_idx) and torch.equal(d1[:4].cpu().long(), ref_d)
+    qlp, rlp = H.pack_labels(ql.cuda()), H.pack_labels(rl.cuda())
+    ap_ref, nrel_ref = H.map_at_k(idx0, qlp, rlp)
+    got = H.hamming_map_at_k(qp, prep, H.PreparedLabels(rlp), qlp, nbits, k)
+    assert got is not None and torch.equal(got[1], nrel_ref) and torch.equal(got[0], ap_ref)
+    calc = CustomCalculator(k=k, distance_metric="hamming", with_faiss=False)
+    m = calc.calculate_maphashing(q.cuda(), ql.cuda(), r.cuda(), rl.cuda(), k)
+    assert abs(m - float(ap_ref.double().mean())) < 1e-9

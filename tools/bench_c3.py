@@ -28,8 +28,16 @@ q, r = synth.structured_codes(ql, nbits, 3, 4), synth.structured_codes(rl, nbits
 qp, rp = H.pack_codes(q.cuda()), H.pack_codes(r.cuda())
 prep = H.PreparedDB(rp, nbits)
 for k in (5000, 117218):
-    us = timeit(lambda: H.hamming_topk(qp, prep, nbits, k, want_dist=False), reps=5)
-    print(f"unsharded: {Q} queries x {N} rows, {nbits} bit, k={k}: {us:9.0f} us  ({Q / us * 1e6:,.0f} queries/s)", flush=True)
+    us = timeit(lambda: H.hamming_topk(qp, rp, nbits, k, want_dist=False), reps=5)
+    print(f"first-generation kernel, whole database: {Q} queries x {N} rows, {nbits} bit, k={k}: {us:9.0f} us  "
+          f"({Q / us * 1e6:,.0f} queries/s)", flush=True)
+us = timeit(lambda: H.hamming_topk(qp, prep, nbits, 5000, want_dist=False), reps=5)
+same = torch.equal(H.hamming_topk(qp, prep, nbits, 5000)[0], H.hamming_topk(qp, rp, nbits, 5000)[0])
+print(f"{len(prep.parts)} virtual shards of {prep.per} rows through the windowed kernel, k=5000: {us:9.0f} us  "
+      f"({Q / us * 1e6:,.0f} queries/s), lists identical: {same}", flush=True)
+qlp0, labs = H.pack_labels(ql.cuda()), H.PreparedLabels(H.pack_labels(rl.cuda()))
+us = timeit(lambda: H.hamming_map_at_k(qp, prep, labs, qlp0, nbits, 5000), reps=5)
+print(f"mAP@5000 through virtual shards + relevance strings: {us:9.0f} us", flush=True)
 idx, _ = H.hamming_topk(qp, prep, nbits, 5000, want_dist=False)
 qlp, rlp = H.pack_labels(ql.cuda()), H.pack_labels(rl.cuda())
 print(f"map_at_k (k=5000, 80 labels = 2 words): {timeit(lambda: H.map_at_k(idx, qlp, rlp)):.0f} us")
