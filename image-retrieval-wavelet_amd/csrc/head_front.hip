@@ -515,9 +515,7 @@ static void launch_front(const HeadFrontPlan &g, const wv_head_params *p, const 
     constexpr size_t lds = (size_t)3 * HF_TILE * sizeof(float);
     static_assert(lds <= (size_t)kMaxLdsBytes, "three tiles must fit the CU's LDS");
     auto kern = k_head_front<NQ, NSC>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // once per process
-    (void)attr;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const f32x4 *stream = reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(p->prepared) + g.qp_bytes);
     hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(B, 32 / NQ)), dim3(256), lds, st, feats, stream, g.wave_stride4,
                        p->in_proj_b + 2 * HF_E, p->attn_out_b, p->q_eff, p->norm1_w, p->norm1_b, p->mlp0_b, p->mlp2_b, x2, B,
