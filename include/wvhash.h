@@ -44,6 +44,10 @@ extern "C" {
 #define WV_LAYOUT_NHWC 1 /* [B][H][W][C]  (PIL / numpy, what np.array(img) yields) */
 
 const char *wv_last_error(void);
+/* 3 = this header.  History: 2 added wv_head_params.q_proj, the host twins, wv_swt2d_forward_ex, the two-step shard entry
+ * points and wv_map_at_k_ld; 3 added wv_head_params.prepared / wv_band_attn_prepare (one-launch head front), the ranking + AP
+ * entry points (wv_hamming_map_at_k, wv_rank_labels_prepare), wv_hamming_shard_prefix / wv_topk_merge_cum_need and the
+ * relevance-string pair of the sharded mAP (wv_hamming_shard_relbits, wv_merge_relbits_map).  A struct gaining a field bumps it. */
 int wv_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
