@@ -252,7 +252,7 @@ _HIP_TYPES = {
 
 
 def get_fusion_head(fusion_config, output_dims):
-    """Same dispatch keys and defaults as the reference (:602-690) for the cross-attention family."""
+    """Same dispatch keys and defaults as the reference (:602-690)."""
     fusion_type = fusion_config.get('type', 'standard')
     embed_dim = fusion_config['output_dim']
     common = dict(
@@ -274,6 +274,8 @@ def get_fusion_head(fusion_config, output_dims):
             query_scale_init=fusion_config.get('query_scale_init', 4.0),
             normalize_queries=fusion_config.get('normalize_queries', True),
             learn_query_scale=fusion_config.get('learn_query_scale', True), **common)
-    raise NotImplementedError(
-        f"fusion type '{fusion_type}' is not part of the accelerated path (wvhash implements the "
-        f"cross-attention bottleneck family: {sorted(_HIP_TYPES)})")
+    # every other type (standard, temperature, semantic, gated, temperature_gated, self_attention, cbam, eca; unknown
+    # names fall back to standard like the reference): stock PyTorch modules with the reference's state_dict keys
+    from .fusion_extra import build_extra_head
+    LOGGER.info("fusion type '%s' runs as stock PyTorch (the HIP head covers the cross-attention family)", fusion_type)
+    return build_extra_head(fusion_type, fusion_config, output_dims)

@@ -121,3 +121,25 @@ def state_sha(sd):
         h.update(k.encode())
         h.update(sd[k].detach().cpu().contiguous().numpy().tobytes())
     return h.hexdigest()
+
+
+def randomize_module(module, seed):
+    """Deterministic, well-scaled values for EVERY parameter and floating-point buffer of a module (sorted by name, one
+    generator): the same call on a structurally identical module -- the reference's class with the same state_dict keys --
+    gives the same numbers, so fixtures need to hold outputs only."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in sorted(module.named_parameters()):
+            if p.dim() > 1:
+                p.copy_(torch.randn(p.shape, generator=g) / (p.shape[-1] ** 0.5))
+            else:
+                scale_like = name.endswith("weight")                 # 1-D weights are norm scales: around one
+                p.copy_(0.1 * torch.randn(p.shape, generator=g) + (1.0 if scale_like else 0.0))
+        for name, b in sorted(module.named_buffers()):
+            if not b.dtype.is_floating_point:
+                continue
+            if name.endswith("running_var"):
+                b.copy_(0.5 + torch.rand(b.shape, generator=g))
+            else:
+                b.copy_(0.1 * torch.randn(b.shape, generator=g))
+    return module

@@ -112,6 +112,35 @@ def make_head_golden():
     np.savez_compressed(os.path.join(HERE, "head_golden.npz"), **out)
 
 
+# --------------------------------------------------------------------------------- the other fusion heads
+def _extra_head_cases():
+    """name, fusion config, input dims, batch, seed -- the table tests/test_fusion_extra.py reads too"""
+    import json
+    with open(os.path.join(HERE, "fusion_extra_cases.json")) as fh:
+        return [(c["name"], c["config"], c["input_dims"], c["batch"], c["seed"]) for c in json.load(fh)]
+
+
+
+def make_fusion_extra_golden():
+    """Outputs of the REFERENCE's non-cross-attention fusion heads (multi_dino_attention.py:156-334) on seeded weights.
+    The weights are made by wvhash.synth.randomize_module on THIS repo's module of the same configuration and loaded into
+    the reference's module with strict=True -- which also pins the state_dict keys -- so the fixture holds outputs only."""
+    from wvhash.models import get_fusion_head
+    mda = load_reference_heads()
+    out = {}
+    for name, cfg, dims, B, seed in _extra_head_cases():
+        mine = synth.randomize_module(get_fusion_head(dict(cfg), list(dims)), seed).eval()
+        ref = mda.get_fusion_head(dict(cfg), list(dims)).eval()
+        ref.load_state_dict(mine.state_dict(), strict=True)
+        g = torch.Generator().manual_seed(seed + 500)
+        feats = [torch.randn(B, d, generator=g) for d in dims]
+        with torch.no_grad():
+            y = ref([f.clone() for f in feats])
+        out[f"{name}/out"] = y.numpy()
+        print(f"extra head {name}: out {tuple(y.shape)} |y|max {y.abs().max():.3f}  keys {len(mine.state_dict())}")
+    np.savez_compressed(os.path.join(HERE, "fusion_extra_golden.npz"), **out)
+
+
 # --------------------------------------------------------------------------------- ranking
 def _cut(path, class_name, names):
     """FunctionDef nodes `names` of `class_name` (or module level when class_name is None), unmodified."""
@@ -316,6 +345,10 @@ def make_swt_golden():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(1)
+    if sys.argv[1:] == ["fusion_extra"]:        # only this fixture (the others are unchanged)
+        make_fusion_extra_golden()
+        sys.exit(0)
+    make_fusion_extra_golden()
     make_swt_golden()
     make_ranking_golden()
     make_head_golden()
