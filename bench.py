@@ -122,29 +122,8 @@ class Pipeline:
         reproducibly per buffer): `candidates` buffers are allocated side by side, the kernel is timed on each (a few
         launches, HIP events) and the fastest one is kept -- setup, before any warm-up or timed step; the probe is reported
         in config.swt_output_placement.  WV_BENCH_SWT_CANDIDATES=1 takes the first allocation as it comes."""
-        from wvhash.transforms import swt2d
-        shape = (4, self.Q, 3, H, W) if self.band_major else (self.Q, 3, 4, H, W)
-        bufs, ms = [], []
-        for _ in range(max(1, candidates)):
-            buf = torch.empty(shape, dtype=torch.float32, device=self.dev)
-            bufs.append(buf)
-            if candidates <= 1:
-                break
-            for _ in range(2):
-                swt2d(self.images, WAVELET, LEVEL, out=buf, band_major=self.band_major)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(4):
-                swt2d(self.images, WAVELET, LEVEL, out=buf, band_major=self.band_major)
-            e1.record()
-            torch.cuda.synchronize()
-            ms.append(round(e0.elapsed_time(e1) / 4, 4))
-        pick = ms.index(min(ms)) if ms else 0
-        best = bufs[pick]
-        info = {"candidates": max(1, candidates), "probe_ms": ms, "picked": pick}
-        del bufs, buf
-        torch.cuda.empty_cache()                         # the other candidates go back to the driver
-        return best, info
+        from wvhash.transforms import swt2d_place_output
+        return swt2d_place_output(self.images, WAVELET, LEVEL, band_major=self.band_major, candidates=candidates)
 
     def stage_swt(self):
         from wvhash.transforms import swt2d

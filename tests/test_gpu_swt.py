@@ -164,3 +164,15 @@ def test_haar_level1_kernel_against_reference_made_lifting_vectors():
     t = 2e-6 * float(x.abs().max())
     assert np.abs(ev[0] - 2 * ll).max() < t and np.abs(ev[1] + hi[0]).max() < t
     assert np.abs(ev[2] + hi[1]).max() < t and np.abs(ev[3] - hi[2] / np.sqrt(2)).max() < t
+
+
+def test_placed_output_buffer_is_a_plain_result_buffer():
+    """swt2d_place_output: the probe returns one of its candidate buffers, of the transform's shape, holding a valid result."""
+    from wvhash.transforms import swt2d_place_output
+    img = torch.from_numpy(synth.natural_images(8, 64, 64, seed=5)).cuda()
+    buf, info = swt2d_place_output(img, "db2", 2, channels_last=True, candidates=3, launches=2)
+    assert tuple(buf.shape) == (8, 3, 4, 64, 64) and info["candidates"] == 3 and len(info["probe_ms"]) == 3
+    assert 0 <= info["picked"] < 3 and min(info["probe_ms"]) == info["probe_ms"][info["picked"]]
+    assert torch.equal(buf, swt2d(img, "db2", 2, channels_last=True))
+    bm, info1 = swt2d_place_output(img, "haar", 1, channels_last=True, band_major=True, candidates=1)
+    assert tuple(bm.shape) == (4, 8, 3, 64, 64) and info1["probe_ms"] == []
