@@ -254,14 +254,17 @@ def evaluate_sharded(net, test_dataset, k=5000, epoch=None, batch_size=64, num_w
     * the search is wvhash.parallel.sharded_hamming_topk: all_gather of the query codes, per-shard histograms and list
       prefixes, all_to_all, GPU merge -- the role faiss.index_cpu_to_all_gpus(shards=True) plays in the reference
       (main/engine/get_knn.py:41-44), whose embedding sweep runs under nn.DataParallel (evaluate.py:70-71);
-    * packed database labels are all-gathered (8 bytes per row), AP is computed for the local queries, the sums and the
-      per-bit counts are all-reduced.
+    * mAP comes from relevance strings (wvhash.parallel.sharded_hamming_map_at_k: a shard ranks against its own rows' labels,
+      1 bit per list entry on the wire) whenever the shape allows -- up to 128 classes, 128 bits, k <= 8192, shards of at
+      most 32,768 rows: MIRFLICKR and COCO at k = 5000; otherwise lists are exchanged, the packed database labels
+      all-gathered (8 bytes per row and label word) and AP computed from the merged lists: the same numbers;
+    * the AP sums and the per-bit counts are all-reduced.
     Returns ``{"test": {"epoch", "maphashing_level0", "bit_balance_level0", "worst_bit_balance_level0"}}``, the same
     numbers as evaluate() on one GPU (lists are identical for every world size; AP sums differ by fp64 rounding only).
     Every rank's query slice is padded to a common length by repeating its last query; the copies are not counted."""
     import torch.distributed as dist
     from torch.utils.data import Subset
-    from ..parallel import sharded_hamming_topk, _all_gather, _all_reduce
+    from ..parallel import sharded_hamming_topk, sharded_hamming_map_at_k, _all_gather, _all_reduce
     from . import hamming as H
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -306,16 +309,23 @@ def evaluate_sharded(net, test_dataset, k=5000, epoch=None, batch_size=64, num_w
     rlp_local = torch.zeros((per_db, lw), dtype=torch.int64, device=dev)
     if r_codes is not None:
         rlp_local[:hi - lo] = H.pack_labels(r_lab.float())
-    if world > 1:
-        rlp_all = torch.empty((world * per_db, lw), dtype=torch.int64, device=dev)
-        _all_gather(rlp_all, rlp_local, group)
-    else:
-        rlp_all = rlp_local
     k_eff = min(int(k), n_db) if k is not None else n_db
-    idx, _ = sharded_hamming_topk(qp, rp, nbits, k_eff, n_db, group=group, want_dist=False)
-    # global row g of shard s sits at row s * per_db + (g - lo_s) of the gathered label table = g (shards are contiguous
-    # slices of equal length per_db, the last one shorter): the gathered table is indexed by the global row directly
-    ap, _ = H.map_at_k(idx, qlp, rlp_all)
+    ap = None
+    if world > 1 and lw in (1, 2) and nbits <= 128 and k_eff <= 8192 and per_db <= H.SHARD_ROWS_MAX:
+        # mAP from relevance strings: no list and no database label leaves its GPU (decided from values every rank shares)
+        shard_labels = H.PreparedLabels(rlp_local[:hi - lo].contiguous()) if hi > lo else None
+        got = sharded_hamming_map_at_k(qp, qlp, H.PreparedDB(rp, nbits), shard_labels, nbits, k_eff, n_db, None, group=group)
+        ap = got[0] if got is not None else None
+    if ap is None:
+        if world > 1:
+            rlp_all = torch.empty((world * per_db, lw), dtype=torch.int64, device=dev)
+            _all_gather(rlp_all, rlp_local, group)
+        else:
+            rlp_all = rlp_local
+        idx, _ = sharded_hamming_topk(qp, rp, nbits, k_eff, n_db, group=group, want_dist=False)
+        # global row g of shard s sits at row s * per_db + (g - lo_s) of the gathered label table = g (shards are contiguous
+        # slices of equal length per_db, the last one shorter): the gathered table is indexed by the global row directly
+        ap, _ = H.map_at_k(idx, qlp, rlp_all)
     sums = torch.zeros(2 + nbits, dtype=torch.float64, device=dev)
     sums[0] = ap[:n_local_q].double().sum()
     sums[1] = float(hi - lo)

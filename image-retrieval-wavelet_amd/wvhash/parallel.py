@@ -204,9 +204,11 @@ def sharded_hamming_map_at_k(q_local, qlab_local, db_shard, labels_shard, nbits,
     merged string exactly as map_at_k evaluates a list.  Per step: one all_gather, one ranking pass per shard, ONE small
     all_to_all (histogram and string side by side: 264 + 136 bytes per query and shard at 8 GPUs instead of 264 + 2,128 in
     two), one merge kernel.
-    q_local int64 [Ql, words]; qlab_local int64 [Ql, 1 or 2] (up to 128 classes); db_shard PreparedDB and labels_shard PreparedLabels of this rank's
-    rows; send_hint: the prefix length (as for sharded_hamming_topk: learn it from an exactly-sized list step, check the
-    returned `need` with exchange_ok)."""
+    q_local int64 [Ql, words]; qlab_local int64 [Ql, 1 or 2] (up to 128 classes: MIRFLICKR's 38 in one label word, COCO's 80
+    in two); db_shard PreparedDB and labels_shard PreparedLabels of this rank's rows; send_hint: the prefix length (learn it
+    from an earlier batch, check the returned `need` with exchange_ok), or None for a one-off call that sizes the exchange
+    exactly first: a histogram pass per shard, one SUM and one MAX all-reduce and one host read (what evaluate_sharded
+    uses) -- `need` is then <= the prefix that was sent by construction."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         out = H.hamming_map_at_k(q_local, db_shard, labels_shard, qlab_local, nbits, k)
@@ -215,14 +217,27 @@ def sharded_hamming_map_at_k(q_local, qlab_local, db_shard, labels_shard, nbits,
     Ql, words = q_local.shape
     lo, hi, per = shard_bounds(n_total, world, rank)
     n_local = hi - lo
-    if per > H.SHARD_ROWS_MAX or k > 8192 or qlab_local.shape[1] > 2 or nbits > 128 or send_hint is None:
+    lwords = qlab_local.shape[1]                         # 1 label word (<= 64 classes) or 2 (COCO's 80, NUS-WIDE's 81)
+    if per > H.SHARD_ROWS_MAX or k > 8192 or lwords not in (1, 2) or nbits > 128:
         return None                                      # decided from values every rank shares: no rank goes another way
     dev = q_local.device
-    both = torch.cat([q_local, qlab_local], dim=1).contiguous()           # codes | label word: one collective
-    both_all = torch.empty((world * Ql, words + 1), dtype=both.dtype, device=dev)
+    both = torch.cat([q_local, qlab_local], dim=1).contiguous()           # codes | label words: one collective
+    both_all = torch.empty((world * Ql, words + lwords), dtype=both.dtype, device=dev)
     _all_gather(both_all, both, group)
-    q_all, ql_all = both_all[:, :words].contiguous(), both_all[:, words:].contiguous()
-    send = max(1, min(min(k, per), int(send_hint)))
+    q_all, ql_all = both_all[:, :words].contiguous(), both_all[:, words:words + lwords].contiguous()
+    kin = min(k, per)
+    if send_hint is None:
+        # exact sizing (one-off calls): every rank learns each query's global k-th distance T from the summed histograms, a
+        # shard's prefix = its rows with distance <= T, the exchange length = the longest prefix anywhere
+        cum = (H.hamming_hist(q_all, db_shard, nbits) if n_local > 0
+               else torch.zeros((world * Ql, nbits + 2), dtype=torch.int32, device=dev))
+        cum_g = cum.clone()
+        _all_reduce(cum_g, dist.ReduceOp.SUM, group)
+        T = (cum_g[:, 1:] >= k).int().argmax(dim=1)
+        owed = torch.gather(cum, 1, (T + 1).unsqueeze(1).long()).max().reshape(1)
+        _all_reduce(owed, dist.ReduceOp.MAX, group)
+        send_hint = int(owed.item())
+    send = max(1, min(kin, int(send_hint)))
     wire = torch.zeros((world * Ql, H.relbits_wire_words(send, nbits)), dtype=torch.int64, device=dev)
     if n_local > 0:
         got = H.hamming_shard_relbits(q_all, db_shard, labels_shard, ql_all, nbits, min(send, n_local), wire=wire, kin=send)
@@ -242,5 +257,7 @@ def exchange_ok(needs, send_hint, kin):
     needs = [n for n in needs if n is not None]
     if not needs:
         return True
-    worst = int(torch.stack([n.reshape(()) for n in needs]).max().item())
+    # the merge kernels report max_g cum[g][T+1] unclamped; a shard never owes more than `kin` = min(k, shard rows) entries
+    # (with many ties at the k-th distance the raw count exceeds it although `kin` entries were exchanged: exact)
+    worst = min(int(torch.stack([n.reshape(()) for n in needs]).max().item()), int(kin))
     return worst <= max(1, min(int(kin), int(send_hint)))

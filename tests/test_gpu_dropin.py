@@ -34,9 +34,9 @@ MODEL_KWARGS = {"backbone_config": {"name": "dinov2_vits14", "frozen": True},
 class SynthHashing(Dataset):
     """{"image","label","path"} items like MIRFlickrHashing.__getitem__ (flikr_coco.py:52-63)."""
 
-    def __init__(self, n, seed, transform, size=(300, 280)):
+    def __init__(self, n, seed, transform, size=(300, 280), classes=38):
         self.imgs = synth.natural_images(n, size[0], size[1], seed=seed)
-        self.labels = synth.multi_hot_labels(n, 38, 0.10, seed)
+        self.labels = synth.multi_hot_labels(n, classes, 0.10, seed)
         self.transform = transform
 
     def __len__(self):

@@ -22,9 +22,12 @@ def _worker(rank, world, port, out_dir):
     from wvhash import parallel, synth
     from wvhash.engine import hamming as H
     out = {}
-    for n_db, nbits, k, ql, prepared in ((25000, 64, 5000, 96, True), (1001, 128, 600, 7, False), (40000, 64, 3000, 5, True)):
-        labels_q = synth.multi_hot_labels(world * ql, 38, 0.1, 1)
-        labels_r = synth.multi_hot_labels(n_db, 38, 0.1, 2)
+    # last case: the c3 shard shape (COCO: 117,218 rows over 8 GPUs = 14,653 rows per shard, 128-bit codes, 80 classes = TWO
+    # label words per row, k = 5000) with as many shards as there are ranks here
+    for n_db, nbits, k, ql, prepared, lc, p in ((25000, 64, 5000, 96, True, 38, 0.1), (1001, 128, 600, 7, False, 38, 0.1),
+                                                (40000, 64, 3000, 5, True, 38, 0.1), (14653 * world, 128, 5000, 40, True, 80, 0.036)):
+        labels_q = synth.multi_hot_labels(world * ql, lc, p, 1)
+        labels_r = synth.multi_hot_labels(n_db, lc, p, 2)
         q, r = synth.structured_codes(labels_q, nbits, 3, 4), synth.structured_codes(labels_r, nbits, 3, 5)
         lo, hi, _ = parallel.shard_bounds(n_db, world, rank)
         qp = H.pack_codes(q[rank * ql:(rank + 1) * ql].cuda())
@@ -44,7 +47,10 @@ def _worker(rank, world, port, out_dir):
             got = parallel.sharded_hamming_map_at_k(qp, qlp, shard, H.PreparedLabels(rlp[lo:hi].contiguous()), nbits, k, n_db, hint)
             ap, nrel, need_m = got
             map_ok = (torch.equal(ap, ap_ref) and torch.equal(nrel, nrel_ref) and parallel.exchange_ok([need_m], hint, min(k, hi - lo + 1)))
-        out[(n_db, nbits, k)] = (torch.equal(idx, full_idx) and torch.equal(d, full_d),
+            # ... and sized exactly by the call itself (send_hint=None: what evaluate_sharded uses)
+            ap_x, nrel_x, _ = parallel.sharded_hamming_map_at_k(qp, qlp, shard, H.PreparedLabels(rlp[lo:hi].contiguous()), nbits, k, n_db, None)
+            map_ok = map_ok and torch.equal(ap_x, ap_ref) and torch.equal(nrel_x, nrel_ref)
+        out[(n_db, nbits, k, lc)] = (torch.equal(idx, full_idx) and torch.equal(d, full_d),
                                  torch.equal(idx_h, full_idx) and torch.equal(d_h, full_d), int(need.item()), hint, map_ok)
     torch.save(out, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
@@ -56,12 +62,13 @@ def test_two_ranks_on_one_gpu_real_kernels(tmp_path):
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for rank in range(2):
         got = torch.load(os.path.join(tmp_path, f"r{rank}.pt"))
-        assert len(got) == 3
+        assert len(got) == 4
         for key, (exact, hinted, need, hint, map_ok) in got.items():
             assert exact and hinted, (rank, key)
             assert need <= hint
             assert map_ok is not False, (rank, key)                  # None: shape not taken by the relevance-string path
-        assert sum(v[4] is True for v in got.values()) >= 1
+        assert sum(v[4] is True for v in got.values()) >= 2
+        assert got[(14653 * 2, 128, 5000, 80)][4] is True            # c3: two label words through parallel.py, AP bit-identical
 
 
 def _eval_worker(rank, world, port, out_dir):
@@ -75,15 +82,17 @@ def _eval_worker(rank, world, port, out_dir):
     from wvhash.engine import evaluate, evaluate_sharded
     from wvhash.transforms import build_transform
     out = {}
-    for defer in (True, False):
+    for defer, classes in ((True, 38), (False, 38), (True, 80)):      # 80 classes (COCO): two label words per row
         tf = build_transform(NODES[0], defer=defer)
-        dts = {"test": SynthHashing(11, 1, tf), "gallery": SynthHashing(45, 2, tf)}      # ragged: 11 queries, 45 rows / 2 ranks
+        dts = {"test": SynthHashing(11, 1, tf, classes=classes),          # ragged: 11 queries, 45 rows / 2 ranks
+               "gallery": SynthHashing(45, 2, tf, classes=classes)}
         net = make_net()
         m = evaluate_sharded(net, dts, k=20, epoch=2, batch_size=8, num_workers=2 if not defer else 0,
                              distance_metric="hamming")
         single = evaluate(net, test_dataset=dts, k=20, epoch=2, batch_size=8, num_workers=0, distance_metric="hamming",
                           exclude=["map", "precision_at_1", "rpr", "pr", "pr_rc", "mean_reciprocal_rank", "r_precision"])
-        out[defer] = (m["test"], {k_: v for k_, v in single["test"].items() if k_ in m["test"]})
+        out[(defer, classes)] = (m["test"], {k_: v for k_, v in single["test"].items() if k_ in m["test"]})
+
     torch.save(out, os.path.join(out_dir, f"e{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

@@ -69,8 +69,8 @@ def _fake_shard_prefix(q_packed, db, nbits, k, workspace=None):
 
 
 def _label_words(rows):
-    """0/1 label rows [n, Lc <= 62] -> one int64 word per row, bit c = class c (pack_labels' layout)."""
-    return (rows.long() << torch.arange(rows.shape[1])).sum(1, keepdim=True)
+    """0/1 label rows [n, Lc <= 128] -> int64 words [n, ceil(Lc / 64)], bit c of word w = class 64 w + c (pack_labels' layout)."""
+    return _pack(rows.float() * 2 - 1)
 
 
 def _wire_words(kin, nbits):
@@ -78,12 +78,12 @@ def _wire_words(kin, nbits):
 
 
 def _fake_shard_relbits(q_packed, db, labels, qlab_packed, nbits, k, wire=None, kin=None):
-    """db: packed codes of the shard; labels: its label words [n, 1]; qlab_packed: label words of the queries [Q, 1].
+    """db: packed codes of the shard; labels: its label words [n, lw]; qlab_packed: label words of the queries [Q, lw].
     Fills the wire rows [histogram as int32 pairs | relevance string] like the kernel does."""
     from oracle import ranking
     kin = k if kin is None else kin
     idx, _ = ranking.hamming_topk_stable(_unpack(q_packed, nbits), _unpack(db, nbits), k)
-    rel = (labels[:, 0][idx] & qlab_packed) != 0                              # [Q, k]
+    rel = ((labels[idx] & qlab_packed.unsqueeze(1)) != 0).any(-1)             # [Q, k]: shares a class in any label word
     Q, W, hw = rel.shape[0], (kin + 63) // 64, (nbits + 3) // 2
     bits = torch.zeros((Q, W * 64), dtype=torch.long)
     bits[:, :k] = rel.long()
@@ -178,7 +178,7 @@ def _worker(rank, world, port, cases, nbits, ql, out_dir):
     dist.destroy_process_group()
 
 
-def _map_worker(rank, world, port, cases, nbits, ql, out_dir):
+def _map_worker(rank, world, port, cases, nbits, ql, out_dir, lc=12, p=0.2):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "image-retrieval-wavelet_amd"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -186,45 +186,50 @@ def _map_worker(rank, world, port, cases, nbits, ql, out_dir):
     from wvhash import parallel, synth
     from wvhash.engine import hamming as H
     H.hamming_shard_relbits, H.merge_relbits_map, H.relbits_wire_words = _fake_shard_relbits, _fake_merge_relbits, _wire_words
+    H.hamming_hist = _fake_hist
     out = {}
     for n_db, k in cases:
         q_all, r = synth.random_codes(world * ql, n_db, nbits, seed=3)
-        ql_all, rl = synth.multi_hot_labels(world * ql, 12, 0.2, 5), synth.multi_hot_labels(n_db, 12, 0.2, 6)
+        ql_all, rl = synth.multi_hot_labels(world * ql, lc, p, 5), synth.multi_hot_labels(n_db, lc, p, 6)
         lo, hi, per = parallel.shard_bounds(n_db, world, rank)
         sl = slice(rank * ql, (rank + 1) * ql)
-        for hint in (min(k, per), 1):
+        for hint in (min(k, per), 1, None):            # None: the exchange is sized exactly first (histograms, two all-reduces)
             ap, nrel, need = parallel.sharded_hamming_map_at_k(_pack(q_all[sl]), _label_words(ql_all[sl]), _pack(r[lo:hi]),
                                                                _label_words(rl[lo:hi]), nbits, k, n_db, hint)
-            out[(n_db, k, hint)] = (ap, nrel, need, max(1, min(min(k, per), hint)))
+            out[(n_db, k, hint)] = (ap, nrel, need, max(1, min(min(k, per), hint)) if hint is not None else min(k, per))
     torch.save(out, os.path.join(out_dir, f"m{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,cases", [(2, [(1000, 300), (1001, 600), (64, 10)]), (3, [(500, 500), (77, 40)])])
-def test_sharded_map_exchange_of_relevance_strings(tmp_path, world, cases):
+@pytest.mark.parametrize("world,cases,nbits,lc,p", [
+    (2, [(1000, 300), (1001, 600), (64, 10)], 64, 12, 0.2), (3, [(500, 500), (77, 40)], 64, 12, 0.2),
+    # the c3 shape class: 128-bit codes and COCO's 80 classes = TWO label words per row next to two code words
+    (2, [(1000, 300), (1001, 600)], 128, 80, 0.036), (3, [(500, 500), (77, 40)], 128, 80, 0.036)])
+def test_sharded_map_exchange_of_relevance_strings(tmp_path, world, cases, nbits, lc, p):
     """The exchange behind sharded_hamming_map_at_k (codes + label words in one all_gather, relevance strings + histograms
-    through two all_to_alls, merge on the receiving rank) with CPU stand-ins for the two kernels: AP and hit counts of the
-    unsharded oracle ranking whenever the reported need fits the prefix that was sent; a prefix of one entry is flagged."""
+    through one all_to_all, merge on the receiving rank) with CPU stand-ins for the two kernels: AP and hit counts of the
+    unsharded oracle ranking whenever the reported need fits the prefix that was sent; a prefix of one entry is flagged.
+    Reference: accuracy_calculator.py:203-231 over get_knn.py:41-44's row shards."""
     from oracle import ranking
     from wvhash import synth
-    nbits, ql = 64, 5
-    port = 31500 + (os.getpid() + world * 11) % 2000
-    mp.spawn(_map_worker, args=(world, port, cases, nbits, ql, str(tmp_path)), nprocs=world, join=True)
+    ql = 5
+    port = 31500 + (os.getpid() + world * 11 + nbits) % 2000
+    mp.spawn(_map_worker, args=(world, port, cases, nbits, ql, str(tmp_path), lc, p), nprocs=world, join=True)
     for rank in range(world):
         got = torch.load(os.path.join(tmp_path, f"m{rank}.pt"))
         for n_db, k in cases:
             q_all, r = synth.random_codes(world * ql, n_db, nbits, seed=3)
-            ql_all, rl = synth.multi_hot_labels(world * ql, 12, 0.2, 5), synth.multi_hot_labels(n_db, 12, 0.2, 6)
+            ql_all, rl = synth.multi_hot_labels(world * ql, lc, p, 5), synth.multi_hot_labels(n_db, lc, p, 6)
             ref_idx, _ = ranking.hamming_topk_stable(q_all, r, k)
             sl = slice(rank * ql, (rank + 1) * ql)
             rel = ((rl[ref_idx[sl]] * ql_all[sl].unsqueeze(1)).sum(-1) > 0).float()
             hits = rel.cumsum(1)
             want = ((hits / torch.arange(1, k + 1).float()) * rel).double().sum(1) / rel.sum(1).clamp(min=1).double()
             per = (n_db + world - 1) // world
-            for hint in (min(k, per), 1):
+            for hint in (min(k, per), 1, None):
                 ap, nrel, need, send = got[(n_db, k, hint)]
-                if int(need.item()) <= send:
+                if min(int(need.item()), min(k, per)) <= send:
                     assert torch.equal(nrel.long(), rel.sum(1).long()) and (ap.double() - want).abs().max() < 1e-6
                 else:
                     assert hint == 1
@@ -232,12 +237,15 @@ def test_sharded_map_exchange_of_relevance_strings(tmp_path, world, cases):
 
 # one process group per world size (spawning costs a torch import per rank), several shapes inside:
 # even shards, a ragged last shard (padding path), k larger than a shard, tiny database
-@pytest.mark.parametrize("world,cases", [(2, [(1000, 300), (1001, 600), (64, 10)]), (3, [(500, 500), (77, 40)])])
-def test_sharded_topk_equals_unsharded(tmp_path, world, cases):
+# nbits = 8: tie-heavy (9 distinct distances over hundreds of rows) -- a shard's count of rows at distance <= T exceeds the
+# `kin` entries that were exchanged although the exchange was exact: exchange_ok must not flag it
+@pytest.mark.parametrize("world,cases,nbits", [(2, [(1000, 300), (1001, 600), (64, 10)], 64), (3, [(500, 500), (77, 40)], 64),
+                                               (2, [(1000, 40), (400, 350)], 8)])
+def test_sharded_topk_equals_unsharded(tmp_path, world, cases, nbits):
     from oracle import ranking
     from wvhash import synth
-    nbits, ql = 64, 5
-    port = 29500 + (os.getpid() + world * 7) % 2000
+    ql = 5
+    port = 29500 + (os.getpid() + world * 7 + nbits) % 2000
     mp.spawn(_worker, args=(world, port, cases, nbits, ql, str(tmp_path)), nprocs=world, join=True)
     for rank in range(world):
         got = torch.load(os.path.join(tmp_path, f"r{rank}.pt"))
