@@ -118,7 +118,7 @@ class Pipeline:
     # -- the stages (each one C-ABI call) ---------------------------------------------------
     def place_swt_output(self, candidates):
         """Where the 4.9 GB sub-band buffer lies in HBM changes the SWT kernel's rate by +-3 % (first allocation of a
-        process: up to +7 %; tools/swt_alloc_test2.py: ten buffers allocated one after the other read 0.99 ... 1.05 ms,
+        process: up to +7 %; tools/swt_alloc_probe2.py: ten buffers allocated one after the other read 0.99 ... 1.05 ms,
         reproducibly per buffer): `candidates` buffers are allocated side by side, the kernel is timed on each (a few
         launches, HIP events) and the fastest one is kept -- setup, before any warm-up or timed step; the probe is reported
         in config.swt_output_placement.  WV_BENCH_SWT_CANDIDATES=1 takes the first allocation as it comes."""

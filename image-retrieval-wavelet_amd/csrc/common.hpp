@@ -16,6 +16,10 @@ namespace wv {
 
 void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 
+// Value of a kernel-selection / tuning switch: always NULL in libwvhash.so (tune_release.cpp), the environment variable of
+// that name in libwvhash_diag.so (tune_diag.cpp).
+const char *tune(const char *name);
+
 #define WV_FAIL(code, ...)          \
     do {                            \
         ::wv::set_error(__VA_ARGS__); \

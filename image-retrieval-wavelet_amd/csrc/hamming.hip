@@ -283,7 +283,7 @@ static int launch_dist_prep(const uint64_t *q, const void *dbP, uint8_t *dist, i
     const int64_t tiles = ceil_div(N, Cfg::TILE);
     while (qch > 2 && tiles * ceil_div(Q, qch) < 4096) qch >>= 1;
     while (qch < 16 && ceil_div(Q, qch) > 65535) qch <<= 1;
-    if (const char *e = getenv("WV_DIST_QCH")) qch = atoi(e);
+    if (const char *e = ::wv::tune("WV_DIST_QCH")) qch = atoi(e);
     switch (qch) {
     case 2: return launch_dist_prep_q<WORDS, 2>(q, dbP, dist, ld, Q, N, st);
     case 4: return launch_dist_prep_q<WORDS, 4>(q, dbP, dist, ld, Q, N, st);
@@ -333,7 +333,7 @@ static int launch_dist(const uint64_t *q, const uint64_t *db, uint8_t *dist, int
     // enough workgroups to fill 256 CUs several times over, but keep >= 8 queries per staged tile
     int qch = 32;
     while (qch > 8 && tiles * ceil_div(Q, qch) < 2048) qch >>= 1;
-    if (const char *e = getenv("WV_DIST_QCH")) qch = std::max(1, atoi(e));
+    if (const char *e = ::wv::tune("WV_DIST_QCH")) qch = std::max(1, atoi(e));
     const int64_t qblocks = ceil_div(Q, qch);
     if (tiles > 0x7fffffff || qblocks > 65535) WV_FAIL(WV_ENOTSUP, "hamming_dist: grid too large");
     const bool aligned = (ld % 16 == 0) && ((reinterpret_cast<uintptr_t>(dist) & 15) == 0);

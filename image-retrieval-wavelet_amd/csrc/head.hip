@@ -761,7 +761,7 @@ static void launch_gemm_panel(const float *A, const float *W, const float *bias,
 // panel, so K is cut until about every CU has one.  C must then hold that many [M][N] partials.
 static int readout_ksplit(int M, int N, int K)
 {
-    if (getenv("WV_GEMM") || K % 64 || N % 96 || M < 128) return 1;
+    if (::wv::tune("WV_GEMM") || K % 64 || N % 96 || M < 128) return 1;
     const int64_t panels = ceil_div(M, 128) * ceil_div(N, 96);
     for (int ks = 8; ks >= 2; ks >>= 1)
         if (K % (ks * 64) == 0 && K / ks >= 128 && panels * ks <= 384) return ks;
@@ -772,7 +772,7 @@ template <int EPI>
 static void launch_gemm(const float *A, const float *W, const float *bias, const float *R, int rmod,
                         float *C, int M, int N, int K, hipStream_t st)
 {
-    const char *force = getenv("WV_GEMM");   // "stream" / "lds" / "panel32" / "panel64" pin a kernel (tests / tuning)
+    const char *force = ::wv::tune("WV_GEMM");   // "stream" / "lds" / "panel32" / "panel64" pin a kernel (tests / tuning)
     const int64_t panels = ceil_div(M, 128) * ceil_div(N, 96);
     const bool panel_ok = K % 64 == 0 && N % 96 == 0 && M >= 128;
     if (panel_ok && force && !strcmp(force, "panel32")) return launch_gemm_panel<32, EPI>(A, W, bias, R, rmod, C, M, N, K, st);
@@ -905,7 +905,7 @@ extern "C" int wv_band_attn_pool(const wv_head_params *p, const float *feats, in
 
     // prepared weights: everything up to x2 in one launch when the batch fills the chip (WV_HEAD_FRONT=0 / 1 pins
     // the separate launches / the one-launch front for tests and A/B runs)
-    const char *pin = getenv("WV_HEAD_FRONT");
+    const char *pin = ::wv::tune("WV_HEAD_FRONT");
     const int mode = pin && !strcmp(pin, "0") ? 0 : pin && !strcmp(pin, "1") ? 1 : -1;
     const bool fused = p->prepared && head_front_launch(p, feats, B, w.x2, mode, st);
     if (!fused) {
@@ -957,8 +957,8 @@ extern "C" int wv_hash_tail(const float *fused, int B, int E, const float *hash_
     WV_REQUIRE(E * sizeof(float) <= 48 * 1024, "hash_tail: E=%d too large", E);
     if (B == 0) return WV_OK;
     const size_t lds16 = ((size_t)4 * E * 4 + (size_t)E * 65) * sizeof(float);
-    const char *pin = getenv("WV_HASH_TAIL");                   // "simple" / "valu16" / "mfma" pin a kernel (tests, A/B runs)
-    const bool simple = getenv("WV_HASH_TAIL_SIMPLE") || (pin && !strcmp(pin, "simple"));
+    const char *pin = ::wv::tune("WV_HASH_TAIL");                   // "simple" / "valu16" / "mfma" pin a kernel (tests, A/B runs)
+    const bool simple = ::wv::tune("WV_HASH_TAIL_SIMPLE") || (pin && !strcmp(pin, "simple"));
     if (!simple && !(pin && !strcmp(pin, "valu16")) && E % 32 == 0 && (B >= 32 || (pin && !strcmp(pin, "mfma")))) {
         const dim3 grid((unsigned)ceil_div(B, 32), (unsigned)ceil_div(nbits, 32));
         hipLaunchKernelGGL(k_hash_tail_mfma, grid, dim3(256), 0, (hipStream_t)stream, fused, B, E, hash_w, hash_b, bn_w, bn_b,

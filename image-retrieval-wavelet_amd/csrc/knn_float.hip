@@ -383,7 +383,7 @@ extern "C" int wv_knn_float(const float *q, const float *db, int Q, int64_t N, i
         const int npass = 6;
         const uint2 *src = bufA;
         uint2 *dst = bufA;
-        const bool select_first = (int64_t)k * 2 <= N && !getenv("WV_KNN_FULLSORT");
+        const bool select_first = (int64_t)k * 2 <= N && !::wv::tune("WV_KNN_FULLSORT");
         if (select_first) {
             // radix-select the k best of every row, then sort only those (the images keep the N-sized pitch)
             const int Ck = (int)ceil_div(k, kRadixThreads);

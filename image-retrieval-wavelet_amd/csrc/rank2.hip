@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256, rank2_min_waves(NC, QB)) void k_rank_window(co
 // which thread count per query a shape takes: 0 = not covered by this kernel
 int rank2_tpq(int Q, int64_t N, int k)
 {
-    const char *force = getenv("WV_TOPK_V2");                   // "0": off, "64" / "256": pin the variant (tests, tuning)
+    const char *force = ::wv::tune("WV_TOPK_V2");                   // "0": off, "64" / "256": pin the variant (tests, tuning)
     if (force && force[0] == '0') return 0;
     if (N >= 65536 || k + 128 >= 65536) return 0;
     const bool fits256 = N <= 256 * 128 && rank2_lds_bytes_per_query<256>(k) <= 100 * 1024;

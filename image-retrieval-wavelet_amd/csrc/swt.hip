@@ -406,7 +406,7 @@ static TilePlan plan_tiles(int B, int C, int H, int W, int L, int n, int in_layo
     int tilesX = (int)ceil_div(W, 128);
     int TW = (int)align_up(ceil_div(W, tilesX), 4);
     int TH = 32;
-    const char *env = getenv("WV_SWT_TILE");  // "TH,TW" override for tuning
+    const char *env = ::wv::tune("WV_SWT_TILE");  // "TH,TW" override for tuning
     int eth = 0, etw = 0;
     if (env && sscanf(env, "%d,%d", &eth, &etw) == 2 && eth > 0 && etw > 0 && etw % 4 == 0) {
         TH = eth; TW = etw;
@@ -535,7 +535,7 @@ static int swt_typed(const void *in, void *out, int B, int C, int H, int W, int 
                      const float *hi, int L, int in_layout, void *ws, size_t ws_bytes, hipStream_t st)
 {
     // WV_SWT_PATH = fused | tiled | generic pins one implementation (tests / tuning); default: best available
-    const char *path = getenv("WV_SWT_PATH");
+    const char *path = ::wv::tune("WV_SWT_PATH");
     const bool want_slide = !path || !strcmp(path, "slide");
     const bool want_fused = !path || !strcmp(path, "fused");
     const bool want_tiled = !path || !strcmp(path, "tiled");
@@ -561,7 +561,7 @@ using namespace wv;
 extern "C" size_t wv_swt2d_workspace_bytes(int B, int C, int H, int W, int level, int flen)
 {
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
-    const char *path = getenv("WV_SWT_PATH");
+    const char *path = ::wv::tune("WV_SWT_PATH");
     if (!path || strcmp(path, "generic")) {
         if (swt_slide_covers(flen, level, W, H) && (!path || !strcmp(path, "slide"))) return 0;
         if (swt_fused_covers(flen, level, W) && (!path || !strcmp(path, "fused"))) return 0;

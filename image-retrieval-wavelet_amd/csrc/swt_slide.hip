@@ -577,20 +577,20 @@ static int launch_slide(const void *in, void *out, SlideGeom g, const float *lo,
         num_cu = prop.multiProcessorCount;
     }
     const int by_lds = std::max<int>(1, (int)((size_t)kMaxLdsBytes / (lds + 512)));
-    const char *env = getenv("WV_SWT_WG_PER_CU");
+    const char *env = ::wv::tune("WV_SWT_WG_PER_CU");
     const int per_cu = env && atoi(env) > 0 ? atoi(env) : std::min(by_lds, std::max(1, MINW * 256 / (2 * NT)));
     const int64_t planes = (int64_t)g.B * g.C;
     int64_t grid = std::min<int64_t>(planes, (int64_t)num_cu * per_cu);
-    const char *cenv = getenv("WV_SWT_COAL");
+    const char *cenv = ::wv::tune("WV_SWT_COAL");
     g.coal = std::is_same<InT, uint8_t>::value && LAYOUT == 0 && R == 16 && g.W % 16 == 0 && g.nrun <= 16 &&
              (int64_t)g.H * g.W % 16 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && !(cenv && atoi(cenv) == 0);
-    const char *xenv = getenv("WV_SWT_XCD");
+    const char *xenv = ::wv::tune("WV_SWT_XCD");
     g.nxcd = xenv ? std::max(1, atoi(xenv)) : 8;
     if (grid < planes) grid -= grid % g.nxcd;      // persistent launch: same number of workgroups on every XCD
     if (grid <= 0 || grid % g.nxcd) g.nxcd = 1, grid = std::min<int64_t>(planes, (int64_t)num_cu * per_cu);
     constexpr bool kHasStampBuild = (L == 4 && NLEV == 3) || (L == 2 && NLEV == 1);   // the two shipped configs
     if constexpr (kHasStampBuild)
-    if (getenv("WV_SWT_STAMPS")) {   // diagnostic build: run once, print where each role's cycles go
+    if (::wv::tune("WV_SWT_STAMPS")) {   // diagnostic build: run once, print where each role's cycles go
         auto kstamp = k_swt_slide<L, NLEV, R, TH, NT, MINW, InT, LAYOUT, BF16, true>;
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kstamp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -384,7 +384,7 @@ static inline size_t rank_fixed_words(int nbins, bool u16)
 // Kept selectable (WV_TOPK_STAGE=1) for shapes where the table is small.
 static inline bool rank_staged(int k, int nbins, bool u16)
 {
-    static const bool enabled = getenv("WV_TOPK_STAGE") && getenv("WV_TOPK_STAGE")[0] == '1';
+    static const bool enabled = ::wv::tune("WV_TOPK_STAGE") && ::wv::tune("WV_TOPK_STAGE")[0] == '1';
     return enabled && k <= kStageMaxK && (rank_fixed_words(nbins, u16) + (size_t)k + 4) * 4 <= (size_t)kMaxLdsBytes - 4096;
 }
 static inline size_t rank_lds_bytes(int nbins, bool u16, int k)
@@ -772,7 +772,7 @@ static int launch_topk(const uint64_t *q, const uint64_t *db, const uint64_t *db
     }
     const bool u16 = rank_u16(N), staged = rank_staged(k, nbins, u16);
     const size_t lds = rank_lds_bytes(nbins, u16, k);
-    if (const char *e = getenv("WV_TOPK_DBG")) {
+    if (const char *e = ::wv::tune("WV_TOPK_DBG")) {
         const int v = atoi(e);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_topk_dbg), &v, sizeof(int));
     }

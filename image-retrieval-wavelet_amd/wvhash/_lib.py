@@ -3,6 +3,7 @@
 The product path has no CPU fallback: if the library is missing or fails to load, every op
 raises ``WvhashUnavailable`` -- it never silently computes on the host.
 """
+import contextlib
 import ctypes
 import os
 
@@ -11,6 +12,9 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # WVHASH_LIB: another build of the same library (A/B measurements of kernel variants, tools/build_variant.sh)
 LIB_PATH = os.environ.get("WVHASH_LIB") or os.path.join(_HERE, "_lib", "libwvhash.so")
+# The same objects linked with csrc/tune_diag.cpp: kernel-selection switches (WV_SWT_PATH, WV_HEAD_FRONT, WV_TOPK_V2, ...) are
+# read from the environment.  The release library has them compiled out; only tests and tools/ load this one (diagnostic()).
+DIAG_LIB_PATH = os.path.join(_HERE, "_lib", "libwvhash_diag.so")
 
 WV_DT_U8, WV_DT_F32, WV_DT_BF16 = 0, 1, 2
 WV_LAYOUT_NCHW, WV_LAYOUT_NHWC = 0, 1
@@ -98,31 +102,52 @@ SIGNATURES = {
 }
 
 _LIB = None
+_DIAG = None
+_USE_DIAG = os.environ.get("WVHASH_DIAG") == "1"      # tools/: run a whole script on the diagnostic build
 
 
-def load():
-    """Load libwvhash.so (after torch, so that both share one HIP runtime)."""
-    global _LIB
-    if _LIB is not None:
-        return _LIB
-    if not os.path.exists(LIB_PATH):
+def _open(path):
+    if not os.path.exists(path):
         raise WvhashUnavailable(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C image-retrieval-wavelet_amd/csrc`. There is no CPU fallback.")
     # torch ships its own libamdhip64 (same SONAME as /opt/rocm's): make sure it is the one mapped
     hip_in_torch = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
     if os.path.exists(hip_in_torch):
         ctypes.CDLL(hip_in_torch, mode=ctypes.RTLD_GLOBAL)
     try:
-        lib = ctypes.CDLL(LIB_PATH)
+        lib = ctypes.CDLL(path)
     except OSError as e:  # pragma: no cover
-        raise WvhashUnavailable(f"cannot load {LIB_PATH}: {e}") from e
+        raise WvhashUnavailable(f"cannot load {path}: {e}") from e
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    _LIB = lib
     return lib
+
+
+def load():
+    """Load libwvhash.so (after torch, so that both share one HIP runtime)."""
+    global _LIB, _DIAG
+    if _USE_DIAG:
+        if _DIAG is None:
+            _DIAG = _open(DIAG_LIB_PATH)
+        return _DIAG
+    if _LIB is None:
+        _LIB = _open(LIB_PATH)
+    return _LIB
+
+
+@contextlib.contextmanager
+def diagnostic():
+    """Inside the block every op goes through libwvhash_diag.so, whose entry points honour the WV_* kernel-selection
+    switches (tests pin each code path with them; tools/ A/B variants).  Never used by the product path."""
+    global _USE_DIAG
+    prev, _USE_DIAG = _USE_DIAG, True
+    try:
+        yield load()
+    finally:
+        _USE_DIAG = prev
 
 
 def require_gpu():

@@ -27,3 +27,13 @@ def _oracle_built():
     if not os.path.exists(so):
         import subprocess
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+
+
+@pytest.fixture
+def diag(monkeypatch):
+    """monkeypatch with the DIAGNOSTIC build of the library active (libwvhash_diag.so: same objects, linked with
+    csrc/tune_diag.cpp): the WV_* switches that pin one kernel variant / code path exist only there -- the release
+    library never reads the environment."""
+    from wvhash import _lib
+    with _lib.diagnostic():
+        yield monkeypatch

@@ -32,6 +32,20 @@ def test_library_exports_every_declared_symbol():
     assert lib.wv_abi_version() == 3
 
 
+def test_release_library_never_reads_the_environment():
+    """include/wvhash.h promises "no global mutable state": the kernel-selection switches (WV_SWT_PATH, WV_HEAD_FRONT,
+    WV_TOPK_V2, ...) exist only in libwvhash_diag.so (csrc/tune_diag.cpp); libwvhash.so does not even import getenv.  Both
+    export the same symbols (they are the same objects but one)."""
+    import subprocess
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undefined
+    assert "getenv" in subprocess.run(["nm", "-D", "--undefined-only", _lib.DIAG_LIB_PATH], capture_output=True, text=True,
+                                      check=True).stdout
+    with _lib.diagnostic() as d:
+        assert d is not _lib._LIB and all(hasattr(d, s) for s in header_symbols())
+    assert _lib.load() is _lib._LIB
+
+
 def test_argument_validation_happens_on_the_host():
     lib = _lib.load()
     one = ctypes.c_void_p(16)  # never dereferenced: validation fails first

@@ -55,9 +55,9 @@ def test_side_stream_is_honoured():
 
 @pytest.mark.parametrize("path", ["slide", "fused", "tiled", "generic"])
 @pytest.mark.parametrize("wl,lev,H_,W_", [("db2", 3, 224, 224), ("haar", 1, 224, 224), ("db2", 3, 64, 96)])
-def test_every_swt_implementation_agrees_with_the_oracle(path, wl, lev, H_, W_, monkeypatch):
+def test_every_swt_implementation_agrees_with_the_oracle(path, wl, lev, H_, W_, diag):
     from wvhash.transforms import swt2d
-    monkeypatch.setenv("WV_SWT_PATH", path)
+    diag.setenv("WV_SWT_PATH", path)
     img = synth.natural_images(2, H_, W_, seed=lev + W_)
     ref = swt_np.c_transform_batch(img, wl, lev)
     x = torch.from_numpy(img).cuda()

@@ -41,10 +41,10 @@ def build(n, gold):
 
 
 @pytest.mark.parametrize("front", ["0", "1"])
-def test_heads_match_reference_module_outputs(gold, front, monkeypatch):
+def test_heads_match_reference_module_outputs(gold, front, diag):
     """front = "1": the one-launch front (csrc/head_front.hip) wherever the configuration has one (E = 384 with 4 or 8
     queries: five of the seven cases); "0": the separate launches for all of them."""
-    monkeypatch.setenv("WV_HEAD_FRONT", front)
+    diag.setenv("WV_HEAD_FRONT", front)
     names = sorted({k.split("/")[0] for k in gold.files if k.endswith("/meta")})
     assert len(names) == 7
     for n in names:
@@ -58,8 +58,8 @@ def test_heads_match_reference_module_outputs(gold, front, monkeypatch):
 
 @pytest.mark.parametrize("front", ["0", "1"])
 @pytest.mark.parametrize("B", [1, 63, 256, 2048])
-def test_batch_sizes_against_oracle(B, front, monkeypatch):
-    monkeypatch.setenv("WV_HEAD_FRONT", front)
+def test_batch_sizes_against_oracle(B, front, diag):
+    diag.setenv("WV_HEAD_FRONT", front)
     sd = synth.head_state(384, 4, "concat", seed=5)
     head = get_fusion_head({"type": "cross_attention_advanced", "output_dim": 384, "num_queries": 4}, [384] * 4)
     head.load_state_dict(sd)
@@ -77,7 +77,7 @@ def test_batch_sizes_against_oracle(B, front, monkeypatch):
 
 @pytest.mark.parametrize("nq,heads,B", [(4, 8, 2048), (4, 8, 1155), (8, 8, 600), (4, 12, 100), (8, 6, 37), (4, 16, 9),
                                         (8, 16, 70), (4, 2, 17)])
-def test_one_launch_front_against_separate_launches_and_oracle(nq, heads, B, monkeypatch):
+def test_one_launch_front_against_separate_launches_and_oracle(nq, heads, B, diag):
     """The fused front folds the K projection into the query tokens and mixes V in registers: same function, other
     summation order.  Both paths must sit within the golden tolerance of the fp64 oracle and within 2e-5 of each other;
     the prepared weight stream covers 1, 2 and 4 score blocks (Nq * heads = 32 ... 128) and partial last workgroups."""
@@ -91,7 +91,7 @@ def test_one_launch_front_against_separate_launches_and_oracle(nq, heads, B, mon
     out = {}
     with torch.no_grad():
         for front in ("1", "0"):
-            monkeypatch.setenv("WV_HEAD_FRONT", front)
+            diag.setenv("WV_HEAD_FRONT", front)
             out[front] = head(dev).cpu()
     assert head._qproj_cache["blob"] is not None                 # this configuration has a prepared stream
     assert not torch.equal(out["0"], out["1"])                   # two different kernels did run
@@ -101,8 +101,8 @@ def test_one_launch_front_against_separate_launches_and_oracle(nq, heads, B, mon
         assert (out[front].double() - ref).abs().max().item() < ATOL, front
 
 
-def test_front_is_chosen_by_batch_size_and_unsupported_shapes_fall_back(monkeypatch):
-    monkeypatch.delenv("WV_HEAD_FRONT", raising=False)
+def test_front_is_chosen_by_batch_size_and_unsupported_shapes_fall_back(diag):
+    diag.delenv("WV_HEAD_FRONT", raising=False)
     head = get_fusion_head({"type": "cross_attention_advanced", "output_dim": 384, "num_queries": 4}, [384] * 4)
     head.load_state_dict(synth.head_state(384, 4, "concat", seed=2))
     head = head.cuda().eval()
@@ -110,11 +110,11 @@ def test_front_is_chosen_by_batch_size_and_unsupported_shapes_fall_back(monkeypa
     big = [f.cuda() for f in synth.band_features(1536, 384, seed=1)]
     with torch.no_grad():
         auto_small, auto_big = head(small), head(big)
-        monkeypatch.setenv("WV_HEAD_FRONT", "0")
+        diag.setenv("WV_HEAD_FRONT", "0")
         sep_small, sep_big = head(small), head(big)
     assert torch.equal(auto_small, sep_small)                    # 8 workgroups: the separate launches
     assert not torch.equal(auto_big, sep_big) and (auto_big - sep_big).abs().max().item() < 2e-5   # 192 workgroups: one launch
-    monkeypatch.setenv("WV_HEAD_FRONT", "1")
+    diag.setenv("WV_HEAD_FRONT", "1")
     other = get_fusion_head({"type": "cross_attention_advanced", "output_dim": 64, "num_queries": 4, "num_heads": 4}, [64] * 4)
     other = other.cuda().eval()                                   # E = 64 has no fused kernel: no blob, separate launches
     with torch.no_grad():
@@ -187,7 +187,7 @@ def test_model_classes_end_to_end_with_stub_backbone():
 
 
 @pytest.mark.parametrize("B,nbits,with_bn", [(64, 64, True), (301, 64, True), (2048, 64, True), (130, 128, False), (77, 48, True)])
-def test_hash_tail_kernels_agree_and_do_not_depend_on_the_batch(B, nbits, with_bn, monkeypatch):
+def test_hash_tail_kernels_agree_and_do_not_depend_on_the_batch(B, nbits, with_bn, diag):
     """Three kernels behind wv_hash_tail: per sample (fmaf chain), 16 samples per workgroup on the VALU (the same chain:
     bit-identical to it), and the matrix-core one (32 samples per workgroup, four k ranges summed in a fixed order: other
     rounding, within 1e-5 of the chain; codes equal wherever the logit is not within 1e-4 of zero).  Whatever the kernel,
@@ -202,7 +202,7 @@ def test_hash_tail_kernels_agree_and_do_not_depend_on_the_batch(B, nbits, with_b
     want = ("logits", "codes", "packed")
     out = {}
     for kern in ("simple", "valu16", "mfma"):
-        monkeypatch.setenv("WV_HASH_TAIL", kern)
+        diag.setenv("WV_HASH_TAIL", kern)
         out[kern] = hash_tail(x, fc, bn, want=want)
     for k in want:
         assert torch.equal(out["valu16"][k], out["simple"][k]), k
@@ -211,11 +211,11 @@ def test_hash_tail_kernels_agree_and_do_not_depend_on_the_batch(B, nbits, with_b
     assert torch.equal(out["mfma"]["codes"][far], out["simple"]["codes"][far])
     from wvhash.engine import hamming as H
     assert torch.equal(out["mfma"]["packed"], H.pack_codes(out["mfma"]["codes"]))
-    monkeypatch.delenv("WV_HASH_TAIL")
+    diag.delenv("WV_HASH_TAIL")
     auto = hash_tail(x, fc, bn, want=want)                       # what callers get: the matrix-core kernel from 32 samples on
     for k in want:
         assert torch.equal(auto[k], out["mfma"][k]), k
-    monkeypatch.setenv("WV_HASH_TAIL", "mfma")
+    diag.setenv("WV_HASH_TAIL", "mfma")
     for lo, hi in ((0, 1), (5, 37), (B - 33, B), (B // 2, B // 2 + 7)):
         part = hash_tail(x[lo:hi].contiguous(), fc, bn, want=want)
         for k in want:
@@ -224,10 +224,10 @@ def test_hash_tail_kernels_agree_and_do_not_depend_on_the_batch(B, nbits, with_b
 
 @pytest.mark.parametrize("ftype", ["cross_attention_advanced", "cross_attention_decoupled"])
 @pytest.mark.parametrize("front", ["0", "1"])
-def test_cached_query_projection_follows_parameter_updates(ftype, front, monkeypatch):
+def test_cached_query_projection_follows_parameter_updates(ftype, front, diag):
     """The projected query tokens are kept between calls (they are parameters); an in-place update of the query
     tokens, of the in-projection or of the query scale must invalidate them."""
-    monkeypatch.setenv("WV_HEAD_FRONT", front)
+    diag.setenv("WV_HEAD_FRONT", front)
     torch.manual_seed(3)
     head = get_fusion_head({"type": ftype, "output_dim": 384, "num_queries": 4, "sub_band_dropout_p": 0.0}, [384] * 4)
     head = head.cuda().eval()

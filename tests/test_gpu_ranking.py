@@ -469,10 +469,10 @@ def _spread_codes(Q, N, nbits, seed):
 @pytest.mark.parametrize("variant", ["256", "64", "0"])
 @pytest.mark.parametrize("Q,N,nbits,k", [(9, 3000, 64, 2500), (5, 3000, 128, 3000), (33, 1000, 64, 37), (6, 257, 32, 257),
                                           (4100, 700, 64, 200)])
-def test_window_kernel_variants_and_multi_window_rankings(monkeypatch, variant, Q, N, nbits, k):
+def test_window_kernel_variants_and_multi_window_rankings(diag, variant, Q, N, nbits, k):
     """WV_TOPK_V2 pins the implementation: 256 / 64 threads per query of the windowed kernel, 0 = first-generation
     kernel.  Spread distances force the window to slide; lists, distance rows and histograms must not change."""
-    monkeypatch.setenv("WV_TOPK_V2", variant)
+    diag.setenv("WV_TOPK_V2", variant)
     q, r = (_spread_codes(Q, N, nbits, seed=N + nbits) if Q < 100 else synth.random_codes(Q, N, nbits, seed=5))
     qp, rp = H.pack_codes(q.cuda()), H.pack_codes(r.cuda())
     ref_idx, ref_d = ranking.hamming_topk_stable(q[:64], r, k)
@@ -580,12 +580,12 @@ def test_ap_of_list_prefixes_equals_ap_of_shorter_lists(Q, N, k, Lc):
                                                    (6, 257, 32, 257, 1, True), (4100, 700, 64, 200, 38, False),
                                                    (11, 32768, 64, 8192, 38, False), (3, 4096, 16, 2048, 10, False),
                                                    (41, 14653, 128, 5000, 80, False), (9, 2000, 64, 700, 128, False)])
-def test_fused_map_at_k_equals_ranking_then_ap(monkeypatch, variant, Q, N, nbits, k, Lc, spread):
+def test_fused_map_at_k_equals_ranking_then_ap(diag, variant, Q, N, nbits, k, Lc, spread):
     """wv_hamming_map_at_k (list built and evaluated in LDS, never written) against wv_hamming_topk + wv_map_at_k: AP and
     hit counts of every query.  256 threads per query use the AP kernel's summation order -- bit-identical; one wave per
     query sums in another order (fp64 partial sums: equal after the final fp32 rounding up to one ulp)."""
     if variant is not None:
-        monkeypatch.setenv("WV_TOPK_V2", variant)
+        diag.setenv("WV_TOPK_V2", variant)
     ql, rl = synth.multi_hot_labels(Q, Lc, 0.12, 11), synth.multi_hot_labels(N, Lc, 0.12, 12)
     if spread:
         q, r = _spread_codes(Q, N, nbits, seed=N + nbits)
