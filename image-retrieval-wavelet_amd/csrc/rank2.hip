@@ -53,6 +53,12 @@ __device__ unsigned long long g_rank2_stamps[8];
 #ifndef WV_R2_W25
 #define WV_R2_W25 5
 #endif
+// Timing ablations (tools/build_variant.sh ... -DWV_R2_ABL=n; results are wrong by construction): 1 = the list is not stored,
+// 2 = nothing is placed either, 3 = nothing is counted either (distance pass + scans of an empty table), 4 = distance pass only,
+// 5 = full kernel but every placement store goes to the lane's own trash slot (no scatter, no bank conflicts)
+#ifndef WV_R2_ABL
+#define WV_R2_ABL 0
+#endif
 constexpr int kWinBins = WV_R2_WINBINS;      // distance bins per window
 constexpr int kWinRows = kWinBins + 1;       // + the dummy row
 constexpr int kMaxBins2 = 130;               // nbits <= 128
@@ -118,8 +124,14 @@ __host__ __device__ inline size_t rank2_lds_bytes_per_query(int k, int bm_words 
 }
 
 // One pass over the database image: distances of QB queries -> bytes in registers (dc[qq][i/4] byte i%4 = item i of this
-// thread; 255 = no item), and this thread's smallest distance per query.
+// thread; 255 = no item), and a lower bound of this thread's smallest distance per query.
 // Image (rank2_prepare): 16 bytes per (row, thread): two consecutive 64-bit codes of the thread, or one 128-bit code.
+// Nothing in the item loop asks whether an item exists (a compare + select per item was 2 of its 7 VALU instructions):
+// slots beyond the thread's C items and the padding items behind row N - 1 (zero codes in the image) get a distance like
+// every other, and are overwritten with 255 afterwards -- one OR per cache WORD with a mask that is uniform (slots >= C)
+// and, in the one or few threads behind the last row, one divergent fix-up.  dmin may therefore include a padding item's
+// distance popcount(q): a bound BELOW the true minimum only opens the first window earlier (bins without rows), which
+// is exact.
 template <int WORDS, int TPQ, int NC, int QB>
 __device__ __forceinline__ void rank2_distances(const uint4 *__restrict__ img, const QCode<WORDS> (&qc)[QB], int64_t N, int C,
                                                 int t, uint32_t (&dc)[QB][NC], uint32_t (&dmin)[QB])
@@ -129,6 +141,7 @@ __device__ __forceinline__ void rank2_distances(const uint4 *__restrict__ img, c
     const int first = t * C;
     const int nvalid = min(C, max(0, (int)N - first));           // N < 65536, first <= 256 * 128: plain ints
     const int rows = WORDS == 1 ? (C + 1) / 2 : C;               // image rows
+    const uint32_t toff = (uint32_t)t * 16u;
 #pragma unroll
     for (int qq = 0; qq < QB; ++qq) {
         dmin[qq] = 255;
@@ -140,7 +153,9 @@ __device__ __forceinline__ void rank2_distances(const uint4 *__restrict__ img, c
         if (bi * UNR < C) {                                      // uniform
             uint4 raw[LPB];
 #pragma unroll
-            for (int u = 0; u < LPB; ++u) raw[u] = img[(int64_t)min(bi * LPB + u, rows - 1) * TPQ + t];
+            for (int u = 0; u < LPB; ++u)                        // uniform row base (SGPRs) + the lane's 32-bit byte offset
+                raw[u] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(img) +
+                                                          (size_t)min(bi * LPB + u, rows - 1) * (TPQ * 16) + toff);
 #pragma unroll
             for (int qq = 0; qq < QB; ++qq) {
 #pragma unroll
@@ -160,13 +175,30 @@ __device__ __forceinline__ void rank2_distances(const uint4 *__restrict__ img, c
                             d = (uint32_t)__popc(v.x ^ (uint32_t)qc[qq].w[0]) + (uint32_t)__popc(v.y ^ (uint32_t)(qc[qq].w[0] >> 32)) +
                                 (uint32_t)__popc(v.z ^ (uint32_t)qc[qq].w[1]) + (uint32_t)__popc(v.w ^ (uint32_t)(qc[qq].w[1] >> 32));
                         }
-                        d = (bi * UNR + u < nvalid) ? d : 255u;  // select, not a branch
-                        dmin[qq] = min(dmin[qq], d);
+                        dmin[qq] = min(dmin[qq], d);             // slots beyond C repeat the thread's last row: real distances
                         word |= d << (8 * j);
                     }
                     dc[qq][bi * (UNR / 4) + u4] = word;
                 }
             }
+        }
+    }
+    // ---- slots that hold no item -> 255.  Uniform part: slots >= C of every thread (scalar masks)
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int keep = min(4, max(0, C - 4 * i));              // item slots of word i below C
+        const uint32_t fill = keep >= 4 ? 0u : (0xffffffffu << (8 * keep));
+#pragma unroll
+        for (int qq = 0; qq < QB; ++qq) dc[qq][i] |= fill;
+    }
+    // ... and the threads behind the database's last row (nvalid < C: the last thread with rows and every one after it)
+    if (nvalid < C) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int keep = min(4, max(0, nvalid - 4 * i));
+            const uint32_t fill = keep >= 4 ? 0u : (0xffffffffu << (8 * keep));
+#pragma unroll
+            for (int qq = 0; qq < QB; ++qq) dc[qq][i] |= fill;
         }
     }
 }
@@ -312,170 +344,35 @@ __device__ __forceinline__ void rank2_ap(const uint16_t *stage, const uint32_t *
     ap_finish<TPQ>(relbits, scratch, R, t, ap_out, nrel_out, [] { group_sync<TPQ>(); });
 }
 
-// Ranks ONE query from its cached distances.  Ends with a group barrier: the LDS region may be reused at once.
-// NC = distance-cache words (4 items each): items per thread C <= 4 * NC
-template <int TPQ, int NC, bool AP = false>
-__device__ __forceinline__ void rank2_one_query(const uint32_t (&dc)[NC], uint32_t dmin, int64_t N, int C,
-                                                int nbins, int k, int64_t idx_offset, int32_t *__restrict__ idx_out,
-                                                uint16_t *__restrict__ rows16_out, uint8_t *__restrict__ dist_out,
-                                                uint32_t *__restrict__ cum_out, uint8_t *lds_raw, int t,
-                                                const uint32_t *__restrict__ cls = nullptr, uint64_t qlabel = 0, uint64_t qlabel_hi = 0,
-                                                float *__restrict__ ap_out = nullptr, int32_t *__restrict__ nrel_out = nullptr,
-                                                uint64_t *__restrict__ relbits_out = nullptr)
+// LDS of one query group: [count table][staged list + trash slots][gbase, tot, misc][relevance bitmap (AP)]
+template <int TPQ>
+__device__ __forceinline__ Rank2Lds rank2_lds(uint8_t *lds_raw, int k)
 {
-    // k == 0: histogram only (cum_out), no list.  rows16_out: the list as 16-bit LOCAL row numbers instead of idx_out.
-    constexpr int ROWB = TPQ * 2;                                // bytes per table row
     Rank2Lds L;
     L.table = reinterpret_cast<uint32_t *>(lds_raw);
-    uint8_t *p = lds_raw + (size_t)kWinRows * ROWB;
+    uint8_t *p = lds_raw + (size_t)kWinRows * TPQ * 2;
     L.stage = reinterpret_cast<uint16_t *>(p);
     p += ((size_t)(k + TPQ) * 2 + 15) / 16 * 16;
     L.gbase = reinterpret_cast<uint32_t *>(p);
     L.tot = L.gbase + kMaxBins2 + 1;
     L.misc = L.tot + kWinBins;
-    uint32_t *bitmap = L.misc + 4;                               // relevance of every item (AP only)
-    R2_STAMP_INIT;
-    if constexpr (AP) rank2_relevance_bitmap<TPQ>(cls, qlabel, qlabel_hi, rank2_bitmap_words(N), t, bitmap);
-    R2_STAMP(6);
-    const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform
-    constexpr int NW = TPQ / 64;                                 // waves per query
-    const int first = t * C;
-    // smallest distance of the query = first bin of the first window
-    dmin = wave_min_u32(dmin);
-    if constexpr (NW > 1) {
-        if (lane == 0) L.misc[wv] = dmin;
-        __syncthreads();
-        dmin = min(min(L.misc[0], L.misc[1]), min(L.misc[2], L.misc[3]));
-    }
-    // bins below the first window are empty
-    for (int b = t; b <= nbins; b += TPQ) L.gbase[b] = b <= (int)dmin ? 0u : 0xffffffffu;
-    int lo = min((int)dmin, nbins - 1);                          // dmin == 255 cannot happen (N >= 1)
-    uint32_t placed = 0;                                         // rows with distance < lo
-    // Cell of thread t inside a table row: dword (t>>6)*32 + (t&31), half (t>>5)&1 -- lanes l and l+32 of a wave share a
-    // dword.  A wave's LDS instruction is served in two groups of 32 lanes; this way each group touches 32 different
-    // banks whatever the bins are (pairing lanes 2j, 2j+1 instead made every atomic a 2-way conflict).
-    const uint32_t cell_addr = (uint32_t)((t >> 6) * 32 + (t & 31)) * 4u;
-    const uint32_t cell_shift = 16u * ((t >> 5) & 1);
-    const uint32_t cell_inc = 1u << cell_shift;
-    char *tbl = reinterpret_cast<char *>(L.table);
-    const uint32_t trash = (uint32_t)(k + t);
+    return L;
+}
 
-    R2_STAMP(0);
-    for (;;) {
-        const bool place = placed < (uint32_t)k;                 // uniform: false = count-only pass (cum requested)
-        // ---- zero the table
-        {
-            uint4 *t4 = reinterpret_cast<uint4 *>(L.table);
-            constexpr int n4 = kWinRows * ROWB / 16;
-            for (int i = t; i < n4; i += TPQ) t4[i] = make_uint4(0, 0, 0, 0);
-        }
-        group_sync<TPQ>();
-        // ---- count: one LDS add per item, into the row of its bin or into the dummy row.  Batches of 8 items (two
-        // cache words): one uniform branch per batch; the adds return nothing, so they simply queue up
-#pragma unroll
-        for (int bw = 0; bw < NC; bw += 2) {
-            if (bw * 4 < C) {                                     // uniform; items >= C of the batch hold 255 -> dummy row
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (bw + (j >> 2) < NC) {
-                        const uint32_t d = (dc[bw + (j >> 2)] >> (8 * (j & 3))) & 0xffu;
-                        const uint32_t b = min(d - (uint32_t)lo, (uint32_t)kWinBins);
-                        __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(tbl + b * ROWB + cell_addr), cell_inc,
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                }
-            }
-        }
-        group_sync<TPQ>();
-        R2_STAMP(1);
-        // ---- per-bin totals (the waves of the group share the bins)
-        for (int b = wv; b < kWinBins; b += NW) {
-            uint32_t s;
-            if constexpr (TPQ == 64) {
-                s = (L.table[b * (TPQ / 2) + (lane & 31)] >> cell_shift) & 0xffffu;
-            } else {
-                const uint2 v = *reinterpret_cast<const uint2 *>(L.table + b * (TPQ / 2) + 2 * lane);   // any 4 cells
-                s = (v.x & 0xffffu) + (v.x >> 16) + (v.y & 0xffffu) + (v.y >> 16);
-            }
-            s = wave_sum_u32(s);
-            if (lane == 0) L.tot[b] = s;
-        }
-        group_sync<TPQ>();
-        // ---- every wave: exclusive scan of the 32 totals (lane b holds bin b), then its own bins' thread scans
-        uint32_t my_tot = lane < kWinBins ? L.tot[lane] : 0u;
-        const uint32_t incl = wave_incl_scan_u32(my_tot);
-        const uint32_t bin_base = placed + incl - my_tot;         // lane b: rows with distance < lo + b
-        const uint32_t win_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        if (wv == 0 && lane < kWinBins && lo + lane + 1 <= nbins) L.gbase[lo + lane + 1] = placed + incl;
-        if (place) {
-            for (int b = wv; b < kWinBins; b += NW) {
-                const uint32_t base_b = (uint32_t)__builtin_amdgcn_readlane((int)bin_base, b);
-                if constexpr (TPQ == 64) {
-                    const uint32_t c = (L.table[b * (TPQ / 2) + (lane & 31)] >> cell_shift) & 0xffffu;
-                    const uint32_t excl = wave_incl_scan_u32(c) - c + base_b;
-                    reinterpret_cast<uint16_t *>(L.table + b * (TPQ / 2))[2 * (lane & 31) + (lane >> 5)] =
-                        (uint16_t)min(excl, 0xffffu);
-                } else {
-                    // lane L scans threads 4L .. 4L+3: four consecutive dwords of the row, the same half of each
-                    const int t0 = 4 * lane, d0 = (t0 >> 6) * 32 + (t0 & 31), sh = 16 * ((t0 >> 5) & 1);
-                    const uint4 v = *reinterpret_cast<const uint4 *>(L.table + b * (TPQ / 2) + d0);
-                    const uint32_t c0 = (v.x >> sh) & 0xffffu, c1 = (v.y >> sh) & 0xffffu, c2 = (v.z >> sh) & 0xffffu,
-                                   c3 = (v.w >> sh) & 0xffffu;
-                    const uint32_t s = c0 + c1 + c2 + c3;
-                    const uint32_t e0 = wave_incl_scan_u32(s) - s + base_b;
-                    const uint32_t e1 = e0 + c0, e2 = e1 + c1, e3 = e2 + c2;
-                    // the other half of these dwords belongs to another lane: 16-bit stores
-                    uint16_t *h = reinterpret_cast<uint16_t *>(L.table + b * (TPQ / 2) + d0) + (sh >> 4);
-                    h[0] = (uint16_t)e0; h[2] = (uint16_t)e1; h[4] = (uint16_t)e2; h[6] = (uint16_t)e3;
-                }
-            }
-            // dummy row: every cell starts at k, so whatever it returns is >= k (trash); k + 128 < 65536 (host check)
-            if (wv == NW - 1) {
-                const uint32_t kk = (uint32_t)k | ((uint32_t)k << 16);
-                for (int i = lane; i < TPQ / 2; i += 64) L.table[kWinBins * (TPQ / 2) + i] = kk;
-            }
-            group_sync<TPQ>();
-            R2_STAMP(2);
-            // ---- placement: returning LDS add = this item's rank, item number into the LDS list (or the trash slot).
-            // Sixteen returning adds are in flight before the first result is used (the round trip is the cost here).
-#pragma unroll
-            for (int bw = 0; bw < NC; bw += 4) {
-                if (bw * 4 < C) {                                 // uniform
-                    uint32_t old[16];
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        old[j] = 0;
-                        if (bw + (j >> 2) < NC) {
-                            const uint32_t d = (dc[bw + (j >> 2)] >> (8 * (j & 3))) & 0xffu;
-                            const uint32_t b = min(d - (uint32_t)lo, (uint32_t)kWinBins);
-                            old[j] = __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(tbl + b * ROWB + cell_addr), cell_inc,
-                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        if (bw + (j >> 2) < NC) {
-                            const uint32_t pos = (old[j] >> cell_shift) & 0xffffu;
-                            L.stage[min(pos, trash)] = (uint16_t)(first + bw * 4 + j);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        R2_STAMP(3);
-        placed += win_total;
-        lo += kWinBins;
-        // uniform exit: the list is complete and nobody asked for the full histogram, or no bins are left
-        if (lo >= nbins || (placed >= (uint32_t)k && !cum_out)) break;
-        group_sync<TPQ>();                                        // table is re-zeroed next
-    }
-    group_sync<TPQ>();
-    // bins beyond the last window processed hold every row (the loop only stops early once placed >= k)
-    // ---- cumulative histogram of all rows (cum[b] = rows with distance < b), for the sharded search
-    if (cum_out)
-        for (int b = t; b <= nbins; b += TPQ) cum_out[b] = min(L.gbase[b], (uint32_t)N);
-    R2_STAMP(4);
+template <int TPQ>
+__device__ __forceinline__ void rank2_zero_table(uint8_t *lds_raw, int t)
+{
+    uint4 *t4 = reinterpret_cast<uint4 *>(lds_raw);
+    constexpr int n4 = kWinRows * TPQ * 2 / 16;
+    for (int i = t; i < n4; i += TPQ) t4[i] = make_uint4(0, 0, 0, 0);
+}
+
+// The ranked list (staged in LDS by rank2_rank) leaves for global memory.
+template <int TPQ>
+__device__ __forceinline__ void rank2_copy_list(uint8_t *lds_raw, int k, int64_t idx_offset, int32_t *__restrict__ idx_out,
+                                                uint16_t *__restrict__ rows16_out, int t)
+{
+    const Rank2Lds L = rank2_lds<TPQ>(lds_raw, k);
     // ---- the ranked list leaves with 16-byte stores
     if (rows16_out) {
         if ((k & 7) == 0 && (reinterpret_cast<uintptr_t>(rows16_out) & 15) == 0) {
@@ -500,11 +397,15 @@ __device__ __forceinline__ void rank2_one_query(const uint32_t (&dc)[NC], uint32
             for (int i = t; i < k; i += TPQ) idx_out[i] = (int32_t)L.stage[i] + off;
         }
     }
-    // ---- distance row from the bin boundaries: dist[p] = b with gbase[b] <= p < gbase[b+1]; 16 positions per thread.
-    // Costs 9 of the kernel's 50 us at c1 (41 us without it: callers that only need the list -- mAP -- leave dist_out
-    // NULL).  A search-free form (boundaries in registers, wave-uniform v_readlane walk with packed byte adds) was
-    // built and measured slower (58 us).
-    if (dist_out) {
+}
+
+// The distance row of the ranked list, regenerated from the bin boundaries: dist[p] = b with gbase[b] <= p < gbase[b+1]; 16
+// positions per thread.  Callers that only need the list -- mAP -- leave dist_out NULL.  A search-free form (boundaries in
+// registers, wave-uniform v_readlane walk with packed byte adds) was built and measured slower.
+template <int TPQ>
+__device__ __forceinline__ void rank2_dist_row(const Rank2Lds &L, int nbins, int k, uint8_t *__restrict__ dist_out, int t)
+{
+    {
         const uintptr_t a0 = reinterpret_cast<uintptr_t>(dist_out);
         for (int p0 = t * 16; p0 < k; p0 += TPQ * 16) {
             int a = 0, z = nbins;                                 // invariant: gbase[a] <= p0 < gbase[z]
@@ -545,10 +446,209 @@ __device__ __forceinline__ void rank2_one_query(const uint32_t (&dc)[NC], uint32
             }
         }
     }
-    R2_STAMP(5);
-    if constexpr (AP) rank2_ap<TPQ>(L.stage, bitmap, L.table, k, t, ap_out, nrel_out, relbits_out);   // the count table is free by now
-    R2_STAMP(7);
-    group_sync<TPQ>();                                            // the next query of the group reuses this LDS
+}
+
+// Ranks ONE query from its cached distances into the staged list in LDS (rank2_copy_list moves it to global memory).
+// Expects the count table zeroed (rank2_zero_table + a group barrier before the first LDS add: the caller's -- the
+// zeroing overlaps the distance pass).  Ends with a group barrier.
+// NC = distance-cache words (4 items each): items per thread C <= 4 * NC
+template <int TPQ, int NC, bool AP = false>
+__device__ __forceinline__ void rank2_rank(uint32_t (&dc)[NC], uint32_t dmin, int64_t N, int C, int nbins, int k,
+                                           uint32_t *__restrict__ cum_out, uint8_t *__restrict__ dist_out, uint8_t *lds_raw, int t,
+                                           const uint32_t *__restrict__ cls = nullptr, uint64_t qlabel = 0, uint64_t qlabel_hi = 0,
+                                           float *__restrict__ ap_out = nullptr, int32_t *__restrict__ nrel_out = nullptr,
+                                           uint64_t *__restrict__ relbits_out = nullptr)
+{
+    constexpr int ROWB = TPQ * 2;                                // bytes per table row
+    const Rank2Lds L = rank2_lds<TPQ>(lds_raw, k);
+    uint32_t *bitmap = L.misc + 4;                               // relevance of every item (AP only)
+    R2_STAMP_INIT;
+    if constexpr (AP) rank2_relevance_bitmap<TPQ>(cls, qlabel, qlabel_hi, rank2_bitmap_words(N), t, bitmap);
+    R2_STAMP(6);
+    const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform
+    constexpr int NW = TPQ / 64;                                 // waves per query
+    const int first = t * C;
+    // smallest distance of the query = first bin of the first window
+    dmin = wave_min_u32(dmin);
+    if constexpr (NW > 1) {
+        if (lane == 0) L.misc[wv] = dmin;
+        __syncthreads();
+        dmin = min(min(L.misc[0], L.misc[1]), min(L.misc[2], L.misc[3]));
+    }
+    // bins below the first window are empty
+    for (int b = t; b <= nbins; b += TPQ) L.gbase[b] = b <= (int)dmin ? 0u : 0xffffffffu;
+    int lo = min((int)dmin, nbins - 1);                          // dmin == 255 cannot happen (N >= 1)
+    uint32_t placed = 0;                                         // rows with distance < lo
+    // Cell of thread t inside a table row: dword (t>>6)*32 + (t&31), half (t>>5)&1 -- lanes l and l+32 of a wave share a
+    // dword.  A wave's LDS instruction is served in two groups of 32 lanes; this way each group touches 32 different
+    // banks whatever the bins are (pairing lanes 2j, 2j+1 instead made every atomic a 2-way conflict).
+    // A cell counts in BYTES of the 16-bit list (2 per item): what a placement add returns is the item's byte offset in
+    // the staged list, no shift between the atomic and the store.  Cells start at 2 * min(rank, k) (2k for the dummy row)
+    // and take at most C <= 128 items: 2 * (k + 128) < 65536 (host check).
+    const uint32_t cell_addr = (uint32_t)((t >> 6) * 32 + (t & 31)) * 4u;
+    const uint32_t cell_shift = 16u * ((t >> 5) & 1);
+    const uint32_t cell_inc = 2u << cell_shift;
+    char *tbl = reinterpret_cast<char *>(L.table);
+    char *stage_b = reinterpret_cast<char *>(L.stage);
+    const uint32_t trash = 2u * (uint32_t)(k + t);
+    const uint32_t k2 = 2u * (uint32_t)k;
+    bool first_window = true;
+
+    R2_STAMP(0);
+    for (;;) {
+        const bool place = placed < (uint32_t)k;                 // uniform: false = count-only pass (cum requested)
+        // ---- count: one LDS add per item, into the row of its bin or into the dummy row.  Batches of 8 items (two
+        // cache words): one uniform branch per batch; the adds return nothing, so they simply queue up.
+        // The row is addressed by the ABSOLUTE distance, clamped from above only (min straight from the cache byte, one
+        // shift-add: 2 VALU instructions per item instead of subtract, clamp, shift-add): in the first window no row lies
+        // below `lo` (it starts at the query's smallest distance); before a later window the cache bytes below it are set
+        // to 255 once (rare: the k-th neighbour of a hashing query lies inside the first 32 bins).
+        if (!first_window) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                uint32_t w = dc[i], m = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m |= (((w >> (8 * j)) & 0xffu) < (uint32_t)lo ? 0xffu : 0u) << (8 * j);
+                dc[i] = w | m;
+            }
+        }
+        const uint32_t hi_bin = (uint32_t)(lo + kWinBins);       // first bin beyond the window = the dummy row
+        char *row0 = tbl + (int)cell_addr - lo * ROWB;           // row of absolute bin b: row0 + b * ROWB
+#pragma unroll
+        for (int bw = 0; bw < NC; bw += 2) {
+            if (bw * 4 < C && (WV_R2_ABL < 3 || WV_R2_ABL == 5 || k < 0)) {         // uniform; items >= C of the batch hold 255 -> dummy row
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (bw + (j >> 2) < NC) {
+                        const uint32_t d = (dc[bw + (j >> 2)] >> (8 * (j & 3))) & 0xffu;
+                        const uint32_t b = min(d, hi_bin);
+                        __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(row0 + b * ROWB), cell_inc,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+        }
+        group_sync<TPQ>();
+        R2_STAMP(1);
+        // ---- per-bin totals and the threads' exclusive prefixes inside each bin
+        uint32_t win_total, bin_base;
+        if constexpr (TPQ == 64) {
+            for (int b = 0; b < kWinBins; ++b) {
+                uint32_t s2 = (L.table[b * (TPQ / 2) + (lane & 31)] >> cell_shift) & 0xffffu;
+                s2 = wave_sum_u32(s2) >> 1;                       // the cells count bytes of the list
+                if (lane == 0) L.tot[b] = s2;
+            }
+            group_sync<TPQ>();
+            const uint32_t my_tot = lane < kWinBins ? L.tot[lane] : 0u;
+            const uint32_t incl = wave_incl_scan_u32(my_tot);
+            bin_base = placed + incl - my_tot;                    // lane b: rows with distance < lo + b
+            win_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (lane < kWinBins && lo + lane + 1 <= nbins) L.gbase[lo + lane + 1] = placed + incl;
+            if (place) {
+                for (int b = 0; b < kWinBins; ++b) {
+                    const uint32_t base_b = (uint32_t)__builtin_amdgcn_readlane((int)bin_base, b);
+                    const uint32_t c = (L.table[b * (TPQ / 2) + (lane & 31)] >> cell_shift) & 0xffffu;
+                    const uint32_t excl = wave_incl_scan_u32(c) - c + 2u * base_b;
+                    reinterpret_cast<uint16_t *>(L.table + b * (TPQ / 2))[2 * (lane & 31) + (lane >> 5)] = (uint16_t)min(excl, k2);
+                }
+            }
+        } else {
+            // Two passes over the wave's bins (wv, wv + NW, ...): totals, then the threads' exclusive prefixes inside each bin.
+            // The phase is a chain of latencies (LDS read -> wave scan -> LDS write, bin after bin: 5 k of the 19 k cycles
+            // a query takes alone on a CU).  Issuing the reads of 2 / 4 / 8 bins before the first scan and running their scans
+            // side by side was built and measured (round 3): no gain at c1 (44.5 us bin by bin, 44.6 / 44.4 / 50.6 us --
+            // from 4 bins on the registers spill); keeping the first pass's prefixes in registers, one scan per bin
+            // instead of two, spills too.  With five workgroups per CU other queries fill the gaps: the launch is bound by
+            // the SUM of the CU's vector-memory, VALU and LDS work, not by this chain.
+            for (int b = wv; b < kWinBins; b += NW) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(L.table + b * (TPQ / 2) + 2 * lane);   // any 4 cells
+                uint32_t s2 = (v.x & 0xffffu) + (v.x >> 16) + (v.y & 0xffffu) + (v.y >> 16);
+                s2 = wave_sum_u32(s2) >> 1;                       // the cells count bytes of the list
+                if (lane == 0) L.tot[b] = s2;
+            }
+            group_sync<TPQ>();
+            const uint32_t my_tot = lane < kWinBins ? L.tot[lane] : 0u;
+            const uint32_t incl = wave_incl_scan_u32(my_tot);
+            bin_base = placed + incl - my_tot;                    // lane b: rows with distance < lo + b
+            win_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (wv == 0 && lane < kWinBins && lo + lane + 1 <= nbins) L.gbase[lo + lane + 1] = placed + incl;
+            if (place) {
+                // lane L scans threads 4L .. 4L+3: four consecutive dwords of the row, the same half of each
+                const int t0 = 4 * lane, d0 = (t0 >> 6) * 32 + (t0 & 31), sh = 16 * ((t0 >> 5) & 1);
+                for (int b = wv; b < kWinBins; b += NW) {
+                    const uint32_t base_b = (uint32_t)__builtin_amdgcn_readlane((int)bin_base, b);
+                    const uint4 v = *reinterpret_cast<const uint4 *>(L.table + b * (TPQ / 2) + d0);
+                    const uint32_t c0 = (v.x >> sh) & 0xffffu, c1 = (v.y >> sh) & 0xffffu, c2 = (v.z >> sh) & 0xffffu,
+                                   c3 = (v.w >> sh) & 0xffffu;
+                    const uint32_t s4 = c0 + c1 + c2 + c3;
+                    // cells restart at 2 * min(rank of the cell's first item, k)
+                    const uint32_t e0 = wave_incl_scan_u32(s4) - s4 + 2u * base_b;
+                    const uint32_t e1 = e0 + c0, e2 = e1 + c1, e3 = e2 + c2;
+                    // the other half of these dwords belongs to another lane: 16-bit stores
+                    uint16_t *h = reinterpret_cast<uint16_t *>(L.table + b * (TPQ / 2) + d0) + (sh >> 4);
+                    h[0] = (uint16_t)min(e0, k2); h[2] = (uint16_t)min(e1, k2); h[4] = (uint16_t)min(e2, k2); h[6] = (uint16_t)min(e3, k2);
+                }
+            }
+        }
+        if (place) {
+            // dummy row: every cell starts at 2k, so whatever it returns is >= 2k (trash); 2 (k + 128) < 65536 (host check)
+            if (wv == NW - 1) {
+                const uint32_t kk = k2 * 0x10001u;
+                for (int i = lane; i < TPQ / 2; i += 64) L.table[kWinBins * (TPQ / 2) + i] = kk;
+            }
+            group_sync<TPQ>();
+            R2_STAMP(2);
+            // ---- placement: returning LDS add = this item's byte offset in the list, item number into the LDS list (or
+            // the trash slot).  Sixteen returning adds are in flight before the first result is used (the round trip is the
+            // cost here).
+#pragma unroll
+            for (int bw = 0; bw < NC; bw += 4) {
+                if (bw * 4 < C && (WV_R2_ABL < 2 || WV_R2_ABL == 5 || k < 0)) {     // uniform
+                    uint32_t old[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        old[j] = 0;
+                        if (bw + (j >> 2) < NC) {
+                            const uint32_t d = (dc[bw + (j >> 2)] >> (8 * (j & 3))) & 0xffu;
+                            const uint32_t b = min(d, hi_bin);
+                            old[j] = __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(row0 + b * ROWB), cell_inc,
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        if (bw + (j >> 2) < NC) {
+                            const uint32_t pos2 = (old[j] >> cell_shift) & 0xffffu;      // byte offset in the list
+                            *reinterpret_cast<uint16_t *>(stage_b + min(WV_R2_ABL == 5 ? (pos2 | 0x1ffffu) : pos2, trash)) =
+                                (uint16_t)(first + bw * 4 + j);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        R2_STAMP(3);
+        placed += win_total;
+        lo += kWinBins;
+        first_window = false;
+        // uniform exit: the list is complete and nobody asked for the full histogram, or no bins are left
+        if (lo >= nbins || (placed >= (uint32_t)k && !cum_out)) break;
+        group_sync<TPQ>();                                        // every add of this window has returned
+        rank2_zero_table<TPQ>(lds_raw, t);
+        group_sync<TPQ>();
+    }
+    group_sync<TPQ>();
+    // bins beyond the last window processed hold every row (the loop only stops early once placed >= k)
+    // ---- cumulative histogram of all rows (cum[b] = rows with distance < b), for the sharded search
+    if (cum_out)
+        for (int b = t; b <= nbins; b += TPQ) cum_out[b] = min(L.gbase[b], (uint32_t)N);
+    if (dist_out) rank2_dist_row<TPQ>(L, nbins, k, dist_out, t);
+    R2_STAMP(4);
+    if constexpr (AP) {
+        rank2_ap<TPQ>(L.stage, bitmap, L.table, k, t, ap_out, nrel_out, relbits_out);   // the count table is free by now
+        R2_STAMP(7);
+        group_sync<TPQ>();                                        // the table (AP scratch) and the bitmap are free again
+    }
 }
 
 // Image for TPQ threads per query, 16 bytes per (row, thread).  64-bit codes: row r2 of thread t = its items 2*r2 and
@@ -608,6 +708,13 @@ int rank2_labels_prepare(const uint64_t *dblab, void *cls, int64_t N, int lwords
 constexpr int rank2_min_waves(int nc, int qb) { return nc * qb <= 8 ? 7 : (nc * qb <= 16 ? 6 : (nc * qb <= 25 ? WV_R2_W25 : (nc * qb <= 32 ? 4 : 3))); }
 
 // AP = true: the instantiation behind wv_hamming_map_at_k (its own kernels: the plain ranking keeps its registers)
+//
+// One query per group of TPQ threads.  A persistent form -- the grid sized to what the chip holds at once, a group looping
+// over queries, the list of query i leaving LDS only after the distance pass of query i + 1 so that its stores drain
+// behind the LDS-only phases -- was built and measured (round 3, c1): 1280 resident workgroups 41.3 us, 2048 one-query
+// workgroups 41.0 us, 1024 workgroups x 2 queries 47.5 us, 256 x 8 96 us.  The hardware's dispatch already is that queue;
+// a query's time is a chain of latencies (12 us for a workgroup alone on its CU) that co-resident workgroups stretch to
+// ~20 us at five per CU, whatever order the phases are issued in.
 template <int WORDS, int TPQ, int NC, int QB, bool AP>
 __global__ __launch_bounds__(256, rank2_min_waves(NC, QB)) void k_rank_window(const uint64_t *__restrict__ q, const uint4 *__restrict__ img,
                                                      int32_t *__restrict__ idx, uint16_t *__restrict__ rows16,
@@ -618,7 +725,8 @@ __global__ __launch_bounds__(256, rank2_min_waves(NC, QB)) void k_rank_window(co
     constexpr int GPW = 256 / TPQ;                              // query groups per workgroup
     const int g = threadIdx.x / TPQ, t = threadIdx.x % TPQ;
     const int q0 = (blockIdx.x * GPW + g) * QB;                 // first query of this group
-    if (GPW > 1 && q0 >= Q) return;                              // whole waves only (TPQ == 64): no barrier is skipped
+    if (q0 >= Q) return;                                         // whole waves only (TPQ == 64): no barrier is skipped
+    uint8_t *lds = reinterpret_cast<uint8_t *>(lds4) + (size_t)g * lds_per_group;
     QCode<WORDS> qc[QB];
 #pragma unroll
     for (int qq = 0; qq < QB; ++qq) {
@@ -631,32 +739,44 @@ __global__ __launch_bounds__(256, rank2_min_waves(NC, QB)) void k_rank_window(co
                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
         }
     }
+    if (k != 0) rank2_zero_table<TPQ>(lds, t);                  // LDS stores in the shadow of the image loads
     uint32_t dc[QB][NC], dmin[QB];
     rank2_distances<WORDS, TPQ, NC, QB>(img, qc, N, C, t, dc, dmin);
-    uint8_t *lds = reinterpret_cast<uint8_t *>(lds4) + (size_t)g * lds_per_group;
 #pragma unroll
     for (int qq = 0; qq < QB; ++qq) {
         const int qi = q0 + qq;
-        if (qi < Q && k == 0)                                    // histogram only
+        if (qi >= Q) break;                                      // uniform over the group
+        if (k == 0) {                                            // histogram only
             rank2_hist_only<TPQ, NC>(dc[qq], N, C, nbins, cum + (int64_t)qi * (nbins + 1), lds, t);
-        else if (qi < Q) {                                       // uniform over the group (and over the workgroup when TPQ = 256)
-            if constexpr (AP) {
-                const uint64_t lw = apx.qlab[(int64_t)qi * apx.lwords], lw2 = apx.lwords > 1 ? apx.qlab[(int64_t)qi * apx.lwords + 1] : 0;
-                const uint64_t ql = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(lw >> 32)) << 32) |
-                                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)lw);
-                const uint64_t ql2 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(lw2 >> 32)) << 32) |
-                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)lw2);
-                rank2_one_query<TPQ, NC, true>(dc[qq], dmin[qq], N, C, nbins, k, idx_offset, idx ? idx + (int64_t)qi * k : nullptr,
-                                               rows16 ? rows16 + (int64_t)qi * k : nullptr, dist ? dist + (int64_t)qi * k : nullptr,
-                                               cum ? cum + (int64_t)qi * (apx.cum_ld ? apx.cum_ld : nbins + 1) : nullptr, lds, t,
-                                               apx.cls, ql, ql2, apx.ap ? apx.ap + qi : nullptr, apx.nrel ? apx.nrel + qi : nullptr,
-                                               apx.relbits ? apx.relbits + (int64_t)qi * (apx.relbits_ld ? apx.relbits_ld : (k + 63) / 64)
-                                                           : nullptr);
-            } else {
-                rank2_one_query<TPQ, NC>(dc[qq], dmin[qq], N, C, nbins, k, idx_offset, idx ? idx + (int64_t)qi * k : nullptr,
-                                         rows16 ? rows16 + (int64_t)qi * k : nullptr, dist ? dist + (int64_t)qi * k : nullptr,
-                                         cum ? cum + (int64_t)qi * (nbins + 1) : nullptr, lds, t);
-            }
+            continue;
+        }
+        if (qq > 0) rank2_zero_table<TPQ>(lds, t);              // (the previous query's rank ended with a group barrier)
+        group_sync<TPQ>();                                       // the count table is zero
+        if (WV_R2_ABL == 4 && k > 0) {                          // ablation: keep the distances alive, stop here
+            uint32_t x = dmin[qq];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) x ^= dc[qq][i];
+            if (x == 0x12345678u && idx) idx[(int64_t)qi * k] = (int32_t)x;
+            continue;
+        }
+        if constexpr (AP) {
+            const uint64_t lw = apx.qlab[(int64_t)qi * apx.lwords], lw2 = apx.lwords > 1 ? apx.qlab[(int64_t)qi * apx.lwords + 1] : 0;
+            const uint64_t ql = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(lw >> 32)) << 32) |
+                                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)lw);
+            const uint64_t ql2 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(lw2 >> 32)) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)lw2);
+            rank2_rank<TPQ, NC, true>(dc[qq], dmin[qq], N, C, nbins, k,
+                                      cum ? cum + (int64_t)qi * (apx.cum_ld ? apx.cum_ld : nbins + 1) : nullptr, nullptr, lds, t,
+                                      apx.cls, ql, ql2, apx.ap ? apx.ap + qi : nullptr, apx.nrel ? apx.nrel + qi : nullptr,
+                                      apx.relbits ? apx.relbits + (int64_t)qi * (apx.relbits_ld ? apx.relbits_ld : (k + 63) / 64)
+                                                  : nullptr);
+        } else {
+            rank2_rank<TPQ, NC>(dc[qq], dmin[qq], N, C, nbins, k, cum ? cum + (int64_t)qi * (nbins + 1) : nullptr,
+                                dist ? dist + (int64_t)qi * k : nullptr, lds, t);
+            if (WV_R2_ABL == 0 || WV_R2_ABL == 5 || k < 0)
+                rank2_copy_list<TPQ>(lds, k, idx_offset, idx ? idx + (int64_t)qi * k : nullptr,
+                                     rows16 ? rows16 + (int64_t)qi * k : nullptr, t);
+            if (qq + 1 < QB) group_sync<TPQ>();                  // the list has left the stage before the next query fills it
         }
     }
 }
@@ -667,7 +787,7 @@ int rank2_tpq(int Q, int64_t N, int k)
 {
     const char *force = ::wv::tune("WV_TOPK_V2");                   // "0": off, "64" / "256": pin the variant (tests, tuning)
     if (force && force[0] == '0') return 0;
-    if (N >= 65536 || k + 128 >= 65536) return 0;
+    if (N >= 65536 || 2 * (k + 128) >= 65536) return 0;         // list cells count bytes in 16 bits
     const bool fits256 = N <= 256 * 128 && rank2_lds_bytes_per_query<256>(k) <= 100 * 1024;
     const bool fits64 = ceil_div(N, 64) <= 64 && 4 * rank2_lds_bytes_per_query<64>(k) <= 100 * 1024;
     if (force && atoi(force) == 64 && fits64) return 64;        // a pinned variant that does not fit the shape is ignored
@@ -701,13 +821,16 @@ static int launch_rank2_qb(const uint64_t *q, const void *img, int32_t *idx, uin
                            int C, int nbins, int k, int64_t idx_offset, uint32_t *cum, const Rank2Ap &apx, hipStream_t st)
 {
     constexpr int GPW = 256 / TPQ;
-    const size_t per_g = rank2_lds_bytes_per_query<TPQ>(k, (apx.ap || apx.relbits) ? rank2_bitmap_words(N) : 0), lds = per_g * GPW;
+    const size_t per_g = rank2_lds_bytes_per_query<TPQ>(k, (apx.ap || apx.relbits) ? rank2_bitmap_words(N) : 0);
+    size_t lds = per_g * GPW;
+    if (const char *pad = ::wv::tune("WV_R2_PAD_LDS")) lds += (size_t)atoi(pad);   // diagnostic build: fewer workgroups per CU
     auto kern = (apx.ap || apx.relbits) ? k_rank_window<WORDS, TPQ, NC, QB, true> : k_rank_window<WORDS, TPQ, NC, QB, false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) WV_FAIL(WV_EHIP, "rank_window: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(Q, GPW * QB)), dim3(256), lds, st, q, (const uint4 *)img, idx, rows16, dist,
+    const int64_t grid = ceil_div(Q, GPW * QB);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, q, (const uint4 *)img, idx, rows16, dist,
                        Q, N, C, nbins, k, idx_offset, cum, (int)per_g, apx);
     WV_CHECK_LAUNCH("k_rank_window");
     return WV_OK;
@@ -718,9 +841,11 @@ static int launch_rank2_nc(const uint64_t *q, const void *img, int32_t *idx, uin
                            int C, int nbins, int k, int64_t idx_offset, uint32_t *cum, const Rank2Ap &apx, hipStream_t st)
 {
     // Sharing one pass over the image between QBMAX queries of a group (ranked one after the other) was measured on
-    // MI355X and is slower at every shape tried (c1: 66 vs 50 us; 16384 x 3125: 176 vs 145 us): the registers of the
-    // extra distance caches cost more occupancy than the saved L2 reads are worth.  The kernel keeps the template
-    // parameter; only QB = 1 is instantiated.
+    // MI355X twice (round 2: c1 66 vs 50 us; round 3, with the distance pass known to be half of the launch -- 20.9 of
+    // 43.7 us with everything after it removed -- and the leaner item loops: 62-64 vs 43-45 us, histogram-only launches 33 vs
+    // 22 us): two distance caches take 168 VGPRs (3 waves per SIMD instead of 5), and what the distance pass needs is
+    // bytes in flight -- it runs at 23 TB/s of L2 -> L1 traffic chip-wide, two thirds of the L2's peak, with a queueing
+    // latency of ~2 us per load -- not fewer loads.  The kernel keeps the template parameter; only QB = 1 is instantiated.
     (void)QBMAX;
     return launch_rank2_qb<WORDS, TPQ, NC, 1>(q, img, idx, rows16, dist, Q, N, C, nbins, k, idx_offset, cum, apx, st);
 }

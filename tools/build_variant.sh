@@ -10,6 +10,7 @@ make -C "$CS" -j8 >/dev/null 2>&1
 mkdir -p "$ROOT/tools/_variants" "$ROOT/build/variant_obj"
 OBJ=$ROOT/build/variant_obj/$NAME.o
 hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I"$CS" "$@" -c -o "$OBJ" "$CS/$SRC" 2>/dev/null
-OTHERS=$(ls "$ROOT"/build/obj/*.o | grep -v "/$(basename "${SRC%.*}").o")
+# variants are diagnostic builds: linked with tune_diag.o (the WV_* switches are read from the environment)
+OTHERS=$(ls "$ROOT"/build/obj/*.o | grep -v "/$(basename "${SRC%.*}").o" | grep -v "/tune_release.o")
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/tools/_variants/$NAME.so" $OBJ $OTHERS
 echo "built tools/_variants/$NAME.so"
