@@ -556,7 +556,10 @@ static int launch_slide(const void *in, void *out, SlideGeom g, const float *lo,
     STaps<L> taps;
     for (int i = 0; i < L; ++i) { taps.lo[i] = lo[i]; taps.hi[i] = hi[i]; }
     g.nrun = (int)ceil_div(g.W, R);
-    g.P = g.nrun * R + 4;                         // multiple of 4; rows hold whole runs
+#ifndef WV_SWT_PITCH_PAD
+#define WV_SWT_PITCH_PAD 4
+#endif
+    g.P = g.nrun * R + WV_SWT_PITCH_PAD;          // multiple of 4; rows hold whole runs
     const size_t lds = (size_t)2 * 2 * TH * g.P * sizeof(float);  // 2 buffers x 2 planes
     // shapes this kernel does not take: the caller falls back to the tiled kernels
     if (lds > (size_t)kMaxLdsBytes - 2048 || TH * g.nrun > NT || g.W > NT) return 1;

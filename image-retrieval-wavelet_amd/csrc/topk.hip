@@ -613,6 +613,30 @@ __global__ __launch_bounds__(256) void k_hit_prefix(const int32_t *__restrict__ 
     }
 }
 
+// One wave: was every shard's prefix long enough for query qi?  T = the query's global k-th distance (first bin b with
+// sum_g cum[g][b + 1] >= k, from the UNclamped histograms); shard g had to send cum[g][T + 1] entries.  The largest such
+// count over all (shard, query) pairs of the launch goes to need_out: the exchange was exact iff it is <= the prefix sent
+// (the caller clamps it to min(k, shard rows) first: with many ties at the k-th distance the raw count exceeds what a
+// shard can owe).  cum_ld: row pitch of the histograms in uint32.
+__device__ __forceinline__ void merge_report_need(const uint32_t *__restrict__ cum, int64_t cum_ld, int G, int Q, int qi, int nbins, int k,
+                                                  int32_t *need_out, int lane)
+{
+    int T = nbins - 1;
+    for (int c = 2; c >= 0; --c) {
+        const int b = 64 * c + lane;
+        uint32_t sb = 0;
+        if (b < nbins)
+            for (int g = 0; g < G; ++g) sb += cum[((int64_t)g * Q + qi) * cum_ld + b + 1];
+        const uint64_t m = __ballot(b < nbins && sb >= (uint32_t)k);
+        if (m) T = 64 * c + __builtin_ctzll(m);
+    }
+    uint32_t nd = 0;
+    for (int g = lane; g < G; g += 64) nd = max(nd, cum[((int64_t)g * Q + qi) * cum_ld + T + 1]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) nd = max(nd, (uint32_t)__shfl_xor((int)nd, d, 64));
+    if (lane == 0) atomicMax(need_out, (int32_t)min(nd, 0x7fffffffu));
+}
+
 // Compact form of the same merge for the sharded search: a shard does not send its distance rows (1 byte per
 // entry) but its cumulative distance histogram (cum[b] = rows of the shard with distance < b, nbins + 1 words per
 // query -- the k_hamming_topk by-product), and its list as 16-bit LOCAL row numbers (shards of <= 65536 rows).
@@ -635,44 +659,7 @@ __global__ __launch_bounds__(256) void k_merge_cum(const uint16_t *__restrict__ 
         start[u] = (int32_t)min(cum[((int64_t)g * Q + qi) * (nbins + 1) + b], (uint32_t)kin);
     }
     __syncthreads();
-    if (need_out && wv == 1) {
-        // Was every shard's prefix long enough?  T = this query's global k-th distance (first bin b with
-        // sum_g cum[g][b + 1] >= k, from the UNclamped histograms); shard g had to send cum[g][T + 1] entries.  The
-        // largest such count over all (shard, query) pairs of this launch goes to need_out: exact iff it is <= kin.
-        int T = nbins - 1;
-        for (int c = 2; c >= 0; --c) {
-            const int b = 64 * c + lane;
-            uint32_t sb = 0;
-            if (b < nbins)
-                for (int g = 0; g < G; ++g) sb += cum[((int64_t)g * Q + qi) * (nbins + 1) + b + 1];
-            const uint64_t m = __ballot(b < nbins && sb >= (uint32_t)k);
-            if (m) T = 64 * c + __builtin_ctzll(m);
-        }
-        uint32_t nd = 0;
-        for (int g = lane; g < G; g += 64) nd = max(nd, cum[((int64_t)g * Q + qi) * (nbins + 1) + T + 1]);
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) nd = max(nd, (uint32_t)__shfl_xor((int)nd, d, 64));
-        if (lane == 0) atomicMax(need_out, (int32_t)min(nd, 0x7fffffffu));
-    }
-    if (need_out && wv == 1) {
-        // Was every shard's prefix long enough?  T = this query's global k-th distance (first bin b with
-        // sum_g cum[g][b + 1] >= k, from the UNclamped histograms); shard g had to send cum[g][T + 1] entries.  The
-        // largest such count over all (shard, query) pairs of this launch goes to need_out: exact iff it is <= kin.
-        int T = nbins - 1;
-        for (int c = 2; c >= 0; --c) {
-            const int b = 64 * c + lane;
-            uint32_t sb = 0;
-            if (b < nbins)
-                for (int g = 0; g < G; ++g) sb += cum[((int64_t)g * Q + qi) * (nbins + 1) + b + 1];
-            const uint64_t m = __ballot(b < nbins && sb >= (uint32_t)k);
-            if (m) T = 64 * c + __builtin_ctzll(m);
-        }
-        uint32_t nd = 0;
-        for (int g = lane; g < G; g += 64) nd = max(nd, cum[((int64_t)g * Q + qi) * (nbins + 1) + T + 1]);
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) nd = max(nd, (uint32_t)__shfl_xor((int)nd, d, 64));
-        if (lane == 0) atomicMax(need_out, (int32_t)min(nd, 0x7fffffffu));
-    }
+    if (need_out && wv == 1) merge_report_need(cum, nbins + 1, G, Q, qi, nbins, k, need_out, lane);
     if (wv == 0) {   // totals per bin and their exclusive scan (up to 3 bins per lane)
         uint32_t t[3] = {0, 0, 0};
         const int b0 = 3 * lane;
@@ -913,22 +900,7 @@ __global__ __launch_bounds__(256) void k_merge_relbits_ap(const uint32_t *__rest
     }
     for (int u = tid; u < mwords; u += 256) M[u] = 0;
     __syncthreads();
-    if (need_out && wv == 1) {
-        int T = nbins - 1;
-        for (int c = 2; c >= 0; --c) {
-            const int b = 64 * c + lane;
-            uint32_t sb = 0;
-            if (b < nbins)
-                for (int g = 0; g < G; ++g) sb += cum[((int64_t)g * Q + qi) * cum_ld + b + 1];
-            const uint64_t m = __ballot(b < nbins && sb >= (uint32_t)k);
-            if (m) T = 64 * c + __builtin_ctzll(m);
-        }
-        uint32_t nd = 0;
-        for (int g = lane; g < G; g += 64) nd = max(nd, cum[((int64_t)g * Q + qi) * cum_ld + T + 1]);
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) nd = max(nd, (uint32_t)__shfl_xor((int)nd, d, 64));
-        if (lane == 0) atomicMax(need_out, (int32_t)min(nd, 0x7fffffffu));
-    }
+    if (need_out && wv == 1) merge_report_need(cum, cum_ld, G, Q, qi, nbins, k, need_out, lane);
     if (wv == 0) {   // totals per bin and their exclusive scan (up to 3 bins per lane)
         uint32_t t[3] = {0, 0, 0};
         const int b0 = 3 * lane;

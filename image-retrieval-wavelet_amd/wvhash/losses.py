@@ -14,7 +14,9 @@ class HashLoss(nn.Module):
     def __init__(self, num_classes=20, embedding_size=64, quant_weight=0.1, scale=15.0, **kwargs):
         super().__init__()
         self.quant_weight, self.scale = quant_weight, scale
-        self.proxies = nn.Parameter(torch.empty(num_classes, embedding_size))
+        # randn first, like the reference (:25-26): the values are overwritten, but the global RNG stream must be consumed the
+        # same way or everything seeded after the loss differs from a reference run with the same seed
+        self.proxies = nn.Parameter(torch.randn(num_classes, embedding_size))
         nn.init.xavier_uniform_(self.proxies)
         cfg = kwargs.get("optimizer") or {"name": "AdamW", "kwargs": {"lr": 1e-4, "weight_decay": 1e-4}}
         name = cfg.get("name", "AdamW") if isinstance(cfg, dict) else getattr(cfg, "name", "AdamW")
@@ -31,3 +33,18 @@ class HashLoss(nn.Module):
     def step(self):
         self.loss_optimizer.step()
         self.loss_optimizer.zero_grad()
+
+    # the proxies' optimizer travels inside the loss's state_dict (hash_loss.py:50-59): a reference-made checkpoint's
+    # loss state loads strictly, and the moments survive a resume
+    def state_dict(self, destination=None, prefix="", keep_vars=False):
+        sd = super().state_dict(destination=destination, prefix=prefix, keep_vars=keep_vars)
+        sd["optimizer_state"] = self.loss_optimizer.state_dict()
+        return sd
+
+    def load_state_dict(self, state_dict, strict=True):
+        state_dict = dict(state_dict)
+        optimizer_state = state_dict.pop("optimizer_state", None)
+        out = super().load_state_dict(state_dict, strict)
+        if optimizer_state is not None:
+            self.loss_optimizer.load_state_dict(optimizer_state)
+        return out

@@ -174,6 +174,54 @@ __global__ __launch_bounds__(256) void kT(float4 *out, size_t n4, float v)
         for (int i = 0; i < 16; ++i) out[base + i * 256 + threadIdx.x] = make_float4(v, v, v, v + i);
 }
 
+// U: F's pattern into the BAND-MAJOR layout [4][planes][H][W] (what the models consume); CHUNK rows per burst
+template <int CHUNK, int NTH>
+__global__ __launch_bounds__(NTH) void kU(float *out, float v, int planes)
+{
+    const size_t band = (size_t)H * W, bstride = (size_t)planes * band;
+    const int t = threadIdx.x;
+    if (t >= W) return;
+    for (int p = blockIdx.x; p < planes; p += gridDim.x) {
+        float *o = out + (size_t)p * band + t;
+        for (int y0 = 0; y0 < H; y0 += CHUNK)
+#pragma unroll
+            for (int i = 0; i < CHUNK; ++i)
+#pragma unroll
+                for (int bd = 0; bd < 4; ++bd) o[bd * bstride + (size_t)(y0 + i) * W] = v + i;
+    }
+}
+// V: two planes side by side per workgroup: 448 threads = 7 full waves (F wastes half of its fourth wave), reference layout
+__global__ __launch_bounds__(448) void kV(float *out, float v, int planes)
+{
+    const size_t band = (size_t)H * W;
+    const int t = threadIdx.x, pl = t / W, x = t - pl * W;
+    for (int p = 2 * blockIdx.x; p < planes; p += 2 * gridDim.x) {
+        float *o = out + (size_t)(p + pl) * 4 * band + x;
+        for (int y0 = 0; y0 < H; y0 += 16)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+#pragma unroll
+                for (int bd = 0; bd < 4; ++bd) o[bd * band + (size_t)(y0 + i) * W] = v + i;
+    }
+}
+// W: F with the planes dealt so that concurrently running workgroups write NEIGHBOURING planes (workgroup w takes planes
+// w, w + G, ...: what F does) vs blocks of consecutive planes per workgroup (w * per .. w * per + per - 1)
+__global__ __launch_bounds__(256) void kW(float *out, float v, int planes)
+{
+    const size_t band = (size_t)H * W;
+    const int t = threadIdx.x;
+    if (t >= W) return;
+    const int per = (planes + gridDim.x - 1) / gridDim.x;
+    for (int p = blockIdx.x * per; p < min(planes, (int)(blockIdx.x + 1) * per); ++p) {
+        float *o = out + (size_t)p * 4 * band + t;
+        for (int y0 = 0; y0 < H; y0 += 16)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+#pragma unroll
+                for (int bd = 0; bd < 4; ++bd) o[bd * band + (size_t)(y0 + i) * W] = v + i;
+    }
+}
+
 int main()
 {
     const int B = 2048;
@@ -182,7 +230,7 @@ int main()
     CK(hipMalloc(&out, n * 4));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int which = 0; which < 19; ++which) {
+    for (int which = 0; which < 26; ++which) {
         float best = 1e9f;
         for (int rep = 0; rep < 5; ++rep) {
             CK(hipEventRecord(e0));
@@ -201,6 +249,13 @@ int main()
             if (which == 16) hipLaunchKernelGGL(kQ, dim3((unsigned)(n / 4 / 256)), dim3(256), 0, 0, (float4 *)out, 1.0f);
             if (which == 17) hipLaunchKernelGGL(kR, dim3((unsigned)(n / 4 / 1024)), dim3(256), 0, 0, (float4 *)out, 1.0f);
             if (which == 18) hipLaunchKernelGGL(kT, dim3(2048), dim3(256), 0, 0, (float4 *)out, n / 4, 1.0f);
+            if (which == 19) hipLaunchKernelGGL((kU<16, 256>), dim3(512), dim3(256), 0, 0, out, 1.0f, 3 * B);
+            if (which == 20) hipLaunchKernelGGL((kU<32, 256>), dim3(512), dim3(256), 0, 0, out, 1.0f, 3 * B);
+            if (which == 21) hipLaunchKernelGGL(kV, dim3(256), dim3(448), 0, 0, out, 1.0f, 3 * B);
+            if (which == 22) hipLaunchKernelGGL(kV, dim3(512), dim3(448), 0, 0, out, 1.0f, 3 * B);
+            if (which == 23) hipLaunchKernelGGL(kW, dim3(512), dim3(256), 0, 0, out, 1.0f, 3 * B);
+            if (which == 24) hipLaunchKernelGGL((kF<0, 256>), dim3(256), dim3(256), 0, 0, out, 1.0f, 3 * B);
+            if (which == 25) hipLaunchKernelGGL((kF<0, 256>), dim3(768), dim3(256), 0, 0, out, 1.0f, 3 * B);
             if (which == 12) hipLaunchKernelGGL((kM<256>), dim3(512), dim3(256), 0, 0, out, 1.0f, 3 * B);
             if (which == 13) hipLaunchKernelGGL((kM<256>), dim3(1024), dim3(256), 0, 0, out, 1.0f, 3 * B);
             if (which == 14) hipLaunchKernelGGL(kN, dim3(512), dim3(256), 0, 0, out, 1.0f, 3 * B);
