@@ -61,6 +61,12 @@ SIGNATURES = {
     "wv_swt2d_forward_cpu": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _fp, _fp, _i]),
     "wv_rawstack_forward_cpu": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i]),
     "wv_dwt2d_forward_cpu": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _fp, _fp, _i]),
+    "wv_pack_bits_cpu": (_i, [_vp, _i64, _vp, _i64, _i, _i, _vp]),
+    "wv_bit_counts_cpu": (_i, [_vp, _i64, _i, _vp]),
+    "wv_hamming_dist_cpu": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _i]),
+    "wv_hamming_topk_cpu": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i64]),
+    "wv_map_at_k_cpu": (_i, [_vp, _i64, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "wv_hit_prefix_cpu": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp]),
     "wv_dwt_out_len": (_i, [_i, _i, _i]),
     "wv_dwt2d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "wv_dwt2d_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _fp, _fp, _i, _vp, _sz, _vp]),

@@ -3,8 +3,9 @@
 get_accuracy_calculator :352-403).
 
 The reference subclasses pytorch_metric_learning's AccuracyCalculator and runs on CPU tensors; this
-class is self-contained (PML is not a dependency), keeps everything on the GPU and routes the
-arithmetic through libwvhash:
+class is self-contained (PML is not a dependency), keeps everything on the GPU -- or, with an explicit ``device='cpu'`` (the
+reference's own configuration, main/engine/evaluate.py:76-81; BASELINE config c0), on the host through the `_cpu` twins
+of the same entry points (csrc/host_rank.cpp; same integers, same AP bits) -- and routes the arithmetic through libwvhash:
   calc_hamming_dist       -> wv_hamming_dist        (:183-186)
   calculate_maphashing    -> wv_hamming_topk + wv_map_at_k   (:203-231, the reported metric)
   calculate_bit_balance / calculate_worst_bit_balance -> wv_bit_counts   (:188-200)
@@ -18,6 +19,7 @@ import torch
 
 from .. import _lib
 from . import hamming as H
+from . import hamming_host as HH
 from .get_knn import get_knn, _to_gpu, _is_pm1
 
 LOGGER = logging.getLogger("RETRIEVAL")
@@ -89,22 +91,35 @@ class CustomCalculator(object):
         self.pr_rc_path, self.last_pr_rc = kwargs.pop("pr_rc_path", "pr_rc.csv"), None
         self.distance_metric = distance_metric
         self.rank_cache = kwargs.pop("rank_cache", None)          # shared by the calculators of evaluate_multi_k
-        # the reference pins the calculator to the CPU (main/engine/evaluate.py:76-81); here the
-        # ranking stage lives on the GPU whatever `device` says
+        # device=None / 'cuda': the ranking stage lives on the GPU.  device='cpu' (what the reference pins its calculator
+        # to, main/engine/evaluate.py:76-81): the host twins of the same entry points -- explicit, never a fallback: without
+        # a GPU and without device='cpu' every metric raises WvhashUnavailable.
         self.requested_device = device
+        self.host = device is not None and torch.device(device).type == "cpu"
+        self.H = HH if self.host else H
+        if self.host and self.rank_cache is not None:
+            raise ValueError("a shared RankCache holds GPU lists: not available with device='cpu'")
         self.original_function_dict = {name[len("calculate_"):]: getattr(self, name)
                                        for name in dir(self) if name.startswith("calculate_")}
         self.check_primary_metrics(include, exclude)
         self.original_function_dict = self.get_function_dict(include, exclude)
         self.curr_function_dict = self.get_function_dict()
         LOGGER.info(f"Initializing CustomCalculator with with_faiss={with_faiss} and "
-                    f"distance_metric={distance_metric} device: cuda (HIP)")
+                    f"distance_metric={distance_metric} device: {'cpu (host twins)' if self.host else 'cuda (HIP)'}")
 
     # ------------------------------------------------------------------ bookkeeping (PML surface)
     @property
     def device(self):
+        if self.host:
+            return torch.device("cpu")
         _lib.require_gpu()
         return torch.device("cuda", torch.cuda.current_device())
+
+    def _dev(self, x):
+        """Tensor on the calculator's device (accuracy_calculator.py:290-293 moves everything to self.device)."""
+        if not self.host:
+            return _to_gpu(x)
+        return (x if torch.is_tensor(x) else torch.as_tensor(x)).detach().cpu()
 
     def check_primary_metrics(self, include=(), exclude=()):
         # unlike PML, names this implementation does not compute are tolerated in `exclude`
@@ -159,13 +174,13 @@ class CustomCalculator(object):
     # ------------------------------------------------------------------ hashing primitives
     def calc_hamming_dist(self, qB, rB):
         """0.5 * (B - qB @ rB.T) for +-1 codes (:183-186) -> fp32 [Q, N] like the reference."""
-        qB, rB = _to_gpu(qB), _to_gpu(rB)
-        return H.hamming_dist(H.pack_codes(qB), H.pack_codes(rB), nbits=qB.shape[1]).float()
+        qB, rB = self._dev(qB), self._dev(rB)
+        return self.H.hamming_dist(self.H.pack_codes(qB), self.H.pack_codes(rB), nbits=qB.shape[1]).float()
 
     def per_bit_balance(self, reference):
-        reference = _to_gpu(reference)
+        reference = self._dev(reference)
         nbits = reference.shape[1]
-        counts = H.bit_counts(H.pack_codes(reference, check=False), nbits)
+        counts = self.H.bit_counts(self.H.pack_codes(reference, check=False), nbits)
         frac_positive = counts.float() / float(reference.shape[0])
         return 1.0 - 2.0 * (frac_positive - 0.5).abs()
 
@@ -180,34 +195,34 @@ class CustomCalculator(object):
         if self.rank_cache is not None:
             return self.rank_cache.lists(query, reference, topk)
         nbits = reference.shape[1]
-        rp = H.pack_codes(reference)
-        if rp.shape[0] > H.SHARD_ROWS_MAX:               # large database: virtual shards through the windowed kernel
-            rp = H.PreparedDB(rp, nbits)
-        return H.hamming_topk(H.pack_codes(query), rp, nbits, topk, want_dist=False)[0]
+        rp = self.H.pack_codes(reference)
+        if rp.shape[0] > self.H.SHARD_ROWS_MAX:          # large database: virtual shards through the windowed kernel
+            rp = self.H.PreparedDB(rp, nbits)
+        return self.H.hamming_topk(self.H.pack_codes(query), rp, nbits, topk, want_dist=False)[0]
 
     @staticmethod
-    def _packed_labels(query_labels, reference_labels):
+    def _packed_labels(query_labels, reference_labels, Hm=H):
         if query_labels.ndim == 1:  # class-id labels: one-hot them onto bits
             classes = torch.unique(torch.cat([query_labels, reference_labels]))
             query_labels = (query_labels.unsqueeze(1) == classes).float()
             reference_labels = (reference_labels.unsqueeze(1) == classes).float()
-        return H.pack_labels(query_labels), H.pack_labels(reference_labels)
+        return Hm.pack_labels(query_labels), Hm.pack_labels(reference_labels)
 
     def _average_precisions(self, idx, query_labels, reference_labels, k=None):
         packed = (self.rank_cache.packed_labels(query_labels, reference_labels) if self.rank_cache is not None
-                  else self._packed_labels(query_labels, reference_labels))
-        return H.map_at_k(idx, *packed, k=k)
+                  else self._packed_labels(query_labels, reference_labels, self.H))
+        return self.H.map_at_k(idx, *packed, k=k)
 
     def _hits(self, idx, query_labels, reference_labels):
         """Running hit counts along the ranked lists, int32 [Q, k] (wv_hit_prefix)."""
-        return H.hit_prefix(idx.int(), *self._packed_labels(query_labels, reference_labels))
+        return self.H.hit_prefix(idx.int(), *self._packed_labels(query_labels, reference_labels, self.H))
 
     def calculate_maphashing(self, query, query_labels, reference, reference_labels, topk,
                              ref_includes_query=False, return_per_query=False, **kwargs):
         while isinstance(topk, (tuple, list)):
             topk = topk[0] if len(topk) else None
-        query, reference = _to_gpu(query), _to_gpu(reference)
-        query_labels, reference_labels = _to_gpu(query_labels), _to_gpu(reference_labels)
+        query, reference = self._dev(query), self._dev(reference)
+        query_labels, reference_labels = self._dev(query_labels), self._dev(reference_labels)
         if topk == "max_bin_count":
             topk = int(self._match_counts(reference_labels, reference_labels).max().item()) - int(ref_includes_query)
         num_ref = reference.shape[0]
@@ -216,14 +231,19 @@ class CustomCalculator(object):
         if num_query == 0:
             raise ZeroDivisionError("calculate_maphashing: no queries")
         ap = None
-        if self.rank_cache is None:
+        nbits = reference.shape[1]
+        if self.rank_cache is None and not self.host and nbits <= 128 and topk <= 8192:
             # one k, nothing to share: ranking and AP in one kernel, the lists never leave the GPU's LDS
             # (same numbers as the two steps below; None = shape outside the fused kernel)
             qlp, rlp = self._packed_labels(query_labels, reference_labels)
-            fused = H.hamming_map_at_k(H.pack_codes(query), H.PreparedDB(H.pack_codes(reference), reference.shape[1]),
-                                       H.PreparedLabels(rlp), qlp, reference.shape[1], topk) if rlp.shape[1] <= 2 else None
-            if fused is not None:
-                ap = fused[0]
+            if rlp.shape[1] <= 2:
+                prepared = H.PreparedDB(H.pack_codes(reference), nbits)
+                fused = H.hamming_map_at_k(H.pack_codes(query), prepared, H.PreparedLabels(rlp), qlp, nbits, topk)
+                if fused is not None:
+                    ap = fused[0]
+                else:                                    # outside the fused kernel: rank with the database already prepared
+                    idx = H.hamming_topk(H.pack_codes(query), prepared, nbits, topk, want_dist=False)[0]
+                    ap, _ = H.map_at_k(idx, qlp, rlp, k=topk)
         if ap is None:
             idx = self._ranked_lists(query, reference, topk)
             ap, _ = self._average_precisions(idx, query_labels, reference_labels, k=topk)
@@ -282,8 +302,8 @@ class CustomCalculator(object):
                                 **kwargs):
         """Full-gallery precision / recall curves along the Hamming ranking (:235-273), averaged over the
         queries that are not lone and have a relevant item; writes the curve, returns 0."""
-        query, reference = _to_gpu(query), _to_gpu(reference)
-        query_labels, reference_labels = _to_gpu(query_labels), _to_gpu(reference_labels)
+        query, reference = self._dev(query), self._dev(reference)
+        query_labels, reference_labels = self._dev(query_labels), self._dev(reference_labels)
         hits = self._hits(self._ranked_lists(query, reference, reference.shape[0])[:, :reference.shape[0]], query_labels,
                           reference_labels)
         ok = hits[:, -1] > 0
@@ -307,8 +327,8 @@ class CustomCalculator(object):
     # ------------------------------------------------------------------ driver (:279-349)
     def get_accuracy(self, query, query_labels, reference, reference_labels,
                      embeddings_come_from_same_source, include=(), exclude=(), return_indices=False):
-        query, reference = _to_gpu(query), _to_gpu(reference)
-        query_labels, reference_labels = _to_gpu(query_labels), _to_gpu(reference_labels)
+        query, reference = self._dev(query), self._dev(reference)
+        query_labels, reference_labels = self._dev(query_labels), self._dev(reference_labels)
 
         if query_labels.ndim == 1 or (query_labels.ndim == 2 and query_labels.size(1) == 1):
             query_labels = query_labels.view(-1)
@@ -339,6 +359,8 @@ class CustomCalculator(object):
             if (self.rank_cache is not None and self.distance_metric == "hamming" and reference.shape[1] <= 128
                     and _is_pm1(reference) and _is_pm1(query)):
                 knn_indices, knn_distances = self.rank_cache.knn(reference, query, num_k, embeddings_come_from_same_source)
+            elif self.host:
+                knn_indices, knn_distances = self._host_knn(reference, query, num_k, embeddings_come_from_same_source)
             else:
                 knn_indices, knn_distances = get_knn(
                     reference, query, num_k, embeddings_come_from_same_source,
@@ -356,6 +378,20 @@ class CustomCalculator(object):
         if return_indices:
             return knn_indices, result
         return result
+
+    def _host_knn(self, reference, query, num_k, same_source):
+        """get_knn (get_knn.py:9-24) on the host: +-1 codes under the hamming metric (what the hashing configs evaluate)."""
+        num_k += int(same_source)
+        nbits = reference.shape[1]
+        if not (self.distance_metric == "hamming" and nbits <= 128 and _is_pm1(reference) and _is_pm1(query)):
+            raise _lib.WvhashUnavailable("device='cpu' covers +-1 codes under distance_metric='hamming'; float k-NN "
+                                         "(cosine / l2) runs on the GPU (device=None)")
+        if num_k > reference.shape[0]:
+            raise RuntimeError(f"selected index k out of range (k={num_k}, references={reference.shape[0]})")
+        idx, dist = HH.hamming_topk(HH.pack_codes(query, check=False), HH.pack_codes(reference, check=False), nbits, num_k)
+        ip = float(nbits) - 2.0 * dist.float()
+        first = int(same_source)
+        return idx[:, first:].long(), ip[:, first:]
 
     def _get_accuracy(self, function_dict, **kwargs):
         return {k: v(**kwargs) for k, v in function_dict.items()}

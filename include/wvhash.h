@@ -44,7 +44,7 @@ extern "C" {
 #define WV_LAYOUT_NHWC 1 /* [B][H][W][C]  (PIL / numpy, what np.array(img) yields) */
 
 const char *wv_last_error(void);
-/* 3 = this header.  History: 2 added wv_head_params.q_proj, the host twins, wv_swt2d_forward_ex, the two-step shard entry
+/* 4 = this header.  History: 4 added the host twins of the ranking side (wv_pack_bits_cpu ... wv_hit_prefix_cpu); 2 added wv_head_params.q_proj, the host twins, wv_swt2d_forward_ex, the two-step shard entry
  * points and wv_map_at_k_ld; 3 added wv_head_params.prepared / wv_band_attn_prepare (one-launch head front), the ranking + AP
  * entry points (wv_hamming_map_at_k, wv_rank_labels_prepare), wv_hamming_shard_prefix / wv_topk_merge_cum_need and the
  * relevance-string pair of the sharded mAP (wv_hamming_shard_relbits, wv_merge_relbits_map).  A struct gaining a field bumps it. */
@@ -100,6 +100,26 @@ int wv_rawstack_forward_cpu(const void *in, int in_dtype, int in_layout, float *
                             int copies);
 int wv_dwt2d_forward_cpu(const void *in, int in_dtype, int in_layout, float *out, int B, int C, int H, int W,
                          int level, const float *dec_lo, const float *dec_hi, int flen);
+
+/* ------------------------------------------------------------------------------------------
+ * Host twins of the ranking-side entry points (BASELINE config c0 is the CPU plumbing case).
+ * The reference's calculator runs on CPU tensors (main/engine/accuracy_calculator.py:279-349 with self.device = cpu,
+ *   main/engine/evaluate.py:76-81); CustomCalculator(device='cpu') -- explicit, never a silent fallback -- runs these.
+ * All pointers are HOST pointers; argument meaning as for the device entry point of the same name (no stream, no
+ * workspace).  Same results bit for bit: packed words, counts, distances and the (distance, row) order are integers; the
+ * average precision sums its fp32 quotients in wv_map_at_k's order.  No HIP call, no thread, no global state.
+ *   wv_pack_bits_cpu     <- wv_pack_bits        wv_bit_counts_cpu   <- wv_bit_counts     wv_hamming_dist_cpu <- wv_hamming_dist
+ *   wv_hamming_topk_cpu  <- wv_hamming_topk (stable counting sort; dist may be NULL)
+ *   wv_map_at_k_cpu      <- wv_map_at_k_ld      wv_hit_prefix_cpu   <- wv_hit_prefix
+ * ------------------------------------------------------------------------------------------ */
+int wv_pack_bits_cpu(const float *src, int64_t ld_src, uint64_t *packed, int64_t rows, int nbits, int mode, int32_t *bad_flag);
+int wv_bit_counts_cpu(const uint64_t *packed, int64_t rows, int nbits, uint32_t *counts);
+int wv_hamming_dist_cpu(const uint64_t *q, const uint64_t *db, uint8_t *dist, int64_t ld_dist, int Q, int64_t N, int words);
+int wv_hamming_topk_cpu(const uint64_t *q, const uint64_t *db, int32_t *idx, uint8_t *dist, int Q, int64_t N, int nbits, int k,
+                        int64_t idx_offset);
+int wv_map_at_k_cpu(const int32_t *idx, int64_t ld, int Q, int k, const uint64_t *qlab, const uint64_t *dblab, int lwords,
+                    float *ap, int32_t *nrel);
+int wv_hit_prefix_cpu(const int32_t *idx, int Q, int k, const uint64_t *qlab, const uint64_t *dblab, int lwords, uint32_t *hits);
 
 /* Decimated multi-level 2-D DWT (DWTTransform, custom_transforms.py:191-205 -> pywt.wavedec2, mode
  * 'symmetric'): the four bands (cA, cH, cV, cD) of the coarsest level.

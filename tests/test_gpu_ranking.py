@@ -691,3 +691,33 @@ def test_databases_beyond_32768_rows_take_virtual_shards(Q, N, nbits, k, Lc):
     calc = CustomCalculator(k=k, distance_metric="hamming", with_faiss=False)
     m = calc.calculate_maphashing(q.cuda(), ql.cuda(), r.cuda(), rl.cuda(), k)
     assert abs(m - float(ap_ref.double().mean())) < 1e-9
+
+
+@pytest.mark.parametrize("Q,N,nbits,k,lc", [(64, 25000, 64, 5000, 38), (33, 5717, 16, 5717, 20), (17, 3000, 128, 700, 80)])
+def test_host_rank_twins_equal_the_kernels(Q, N, nbits, k, lc):
+    """csrc/host_rank.cpp (CustomCalculator(device='cpu')) and the gfx950 kernels return the same bits: packed words, per-bit
+    counts, distance matrix, ranked lists + distance rows, running hit counts -- and the average precision, whose fp32
+    quotients the twin sums in k_map_at_k's order (thread, wave butterfly, waves)."""
+    from wvhash.engine import hamming_host as HH
+    ql, rl = synth.multi_hot_labels(Q, lc, 0.1, 21), synth.multi_hot_labels(N, lc, 0.1, 22)
+    q, r = synth.structured_codes(ql, nbits, 3, 23), synth.structured_codes(rl, nbits, 3, 24)
+    qp, rp = H.pack_codes(q.cuda()), H.pack_codes(r.cuda())
+    qh, rh = HH.pack_codes(q), HH.pack_codes(r)
+    assert torch.equal(qp.cpu(), qh) and torch.equal(rp.cpu(), rh)
+    assert torch.equal(H.bit_counts(rp, nbits).cpu(), HH.bit_counts(rh, nbits))
+    assert torch.equal(H.hamming_dist(qp, rp, nbits).cpu(), HH.hamming_dist(qh, rh, nbits))
+    idx, d = H.hamming_topk(qp, rp, nbits, k)
+    idx_h, d_h = HH.hamming_topk(qh, rh, nbits, k)
+    assert torch.equal(idx.cpu(), idx_h) and torch.equal(d.cpu(), d_h)
+    qlp, rlp = H.pack_labels(ql.cuda()), H.pack_labels(rl.cuda())
+    qlh, rlh = HH.pack_labels(ql), HH.pack_labels(rl)
+    assert torch.equal(qlp.cpu(), qlh) and torch.equal(rlp.cpu(), rlh)
+    ap, nrel = H.map_at_k(idx, qlp, rlp)
+    ap_h, nrel_h = HH.map_at_k(idx_h, qlh, rlh)
+    assert torch.equal(nrel.cpu(), nrel_h) and torch.equal(ap.cpu(), ap_h)          # bit-identical floats
+    assert torch.equal(H.hit_prefix(idx, qlp, rlp).cpu(), HH.hit_prefix(idx_h, qlh, rlh))
+    # the two calculators report the same metric
+    from wvhash.engine import CustomCalculator
+    m_gpu = CustomCalculator(k=k, distance_metric="hamming", with_faiss=False).calculate_maphashing(q, ql, r, rl, k)
+    m_cpu = CustomCalculator(k=k, device="cpu", distance_metric="hamming", with_faiss=False).calculate_maphashing(q, ql, r, rl, k)
+    assert abs(m_gpu - m_cpu) < 1e-9
