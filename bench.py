@@ -18,14 +18,20 @@ is row-sharded N ways; all_gather of the packed query codes, per-shard ranking o
 all_to_all of the per-shard lists, GPU merge (wvhash/parallel.py).  value = N*Q / step time.
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, live HIP-event timing),
-"kernels" (every stage), "cpu_baseline" (the oracle = CPU port of the reference's op sequence, timed
-on this host's cores on a bounded sample, N = 1 only).
+"kernels" (every stage of the step, then rows "not in the step": the other BASELINE shapes -- c0, c3 -- and SURVEY 8(d)'s
+grid of wavelets / batch sizes / head shapes, and the deferred SharedDinoHashing pipeline with a random-init ViT-S/14
+consuming the sub-bands), "cpu_baseline" (the oracle = CPU port of the reference's op sequence, timed on this host's cores
+on a bounded sample, N = 1 only).  N = 1 also reports "value_first_allocation": the same K steps timed BEFORE the two
+setup steps that lift "value" (placement probe of the sub-band buffer, clock-ramp steps).  N > 1: config.exchange carries
+the collectives counted per timed step and per-rank kernel / collective milliseconds.
 """
 import argparse
 import json
 import os
 import sys
 import time
+import traceback
+import warnings
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "image-retrieval-wavelet_amd")):
@@ -38,6 +44,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 measured copy)
 F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 (fp32 in/acc)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 (the PyTorch ViT of the deferred-pipeline row; not a kernel of this library)
 
 Q_PER_GPU, N_DB, NBITS, TOPK, N_CLASSES = 2048, 25000, 64, 5000, 38
 H = W = 224
@@ -56,6 +63,7 @@ def parse():
                          "ranking 63 -> 49 us, the HBM-bound SWT unchanged); 0 = measure the ramp")
     ap.add_argument("--queries", type=int, default=Q_PER_GPU, help="query images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-grid", action="store_true", help="skip the kernel rows that are not part of the step (c0 / c3 / SURVEY 8(d) grid)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("WV_BENCH_STREAMS", "1")), choices=(1, 2),
                     help="2: the SWT of a batch runs on its own HIP stream beside head/hash/ranking (stage pipelining)")
     ap.add_argument("--kernel-reps", type=int, default=10, help="launches per stage for the roofline timing")
@@ -68,14 +76,15 @@ class Pipeline:
         from wvhash.engine import hamming as Hm
         from wvhash.models import get_fusion_head
         from wvhash.parallel import shard_bounds
+        if os.environ.get("WV_BENCH_FAIL_SETUP_RANK") == str(rank):      # tests: a rank that dies during setup
+            raise RuntimeError("injected setup failure (WV_BENCH_FAIL_SETUP_RANK)")
         self.Q, self.rank, self.world, self.dev = Q, rank, world, device
         self.swt_stream = torch.cuda.Stream(device=device) if streams == 2 else None
         self.band_major = os.environ.get("WV_BENCH_SWT_LAYOUT", "ref") == "band"       # A/B: the layout the models consume
         g = torch.Generator(device="cpu").manual_seed(1234 + rank)
         self.images = torch.randint(0, 256, (Q, 3, H, W), generator=g, dtype=torch.uint8).to(device)
-        # (ranks rehearsing on ONE shared GPU over gloo take the first allocation: their probes would time each other)
-        shared = world > 1 and os.environ.get("WV_DIST_BACKEND", "nccl") != "nccl"
-        self.bands, self.placement = self.place_swt_output(1 if shared else int(os.environ.get("WV_BENCH_SWT_CANDIDATES", "8")))
+        # the sub-band buffer as it comes (tune_placement() may replace it later)
+        self.bands, self.placement = self.place_swt_output(1)
         # the four backbones' CLS features, resident as slices of one [4, Q, E] buffer (what a pipeline that hands
         # each backbone an output slice produces): the head reads them in place
         self.feats = list(torch.stack(synth.band_features(Q, EMBED, seed=100 + rank)).to(device).unbind(0))
@@ -123,7 +132,16 @@ class Pipeline:
         launches, HIP events) and the fastest one is kept -- setup, before any warm-up or timed step; the probe is reported
         in config.swt_output_placement.  WV_BENCH_SWT_CANDIDATES=1 takes the first allocation as it comes."""
         from wvhash.transforms import swt2d_place_output
-        return swt2d_place_output(self.images, WAVELET, LEVEL, band_major=self.band_major, candidates=candidates)
+        return swt2d_place_output(self.images, WAVELET, LEVEL, band_major=self.band_major, candidates=candidates,
+                                  first=getattr(self, "bands", None))
+
+    def tune_placement(self):
+        """The setup step a long-running service does once: probe candidate allocations, keep the fastest.
+        (Ranks rehearsing on ONE shared GPU over gloo keep the first allocation: their probes would time each other.)"""
+        shared = self.world > 1 and os.environ.get("WV_DIST_BACKEND", "nccl") != "nccl"
+        n = 1 if shared else int(os.environ.get("WV_BENCH_SWT_CANDIDATES", "8"))
+        if n > 1:
+            self.bands, self.placement = self.place_swt_output(n)
 
     def stage_swt(self):
         from wvhash.transforms import swt2d
@@ -298,12 +316,17 @@ def kernel_table(p, reps, swt_ms_live):
                      8 * Q * N_DB + (8 * Q + N_DB) * NBITS // 8,
                      time_stage(lambda: p.Hm.hamming_dist(q8, p.db_packed_full), reps), "timed alone, back to back"))
         del q8
+    return finish_rows(rows)
+
+
+def finish_rows(rows):
     out = []
     for name, bound, work, ms, how in rows:
         if bound == "hbm":
             ach, peak, unit = work / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
         else:
-            ach, peak, unit = work / (ms * 1e-3) / 1e12, F32_MFMA_PEAK_TFLOPS, "TFLOP/s"
+            ach, peak, unit = work / (ms * 1e-3) / 1e12, (BF16_MFMA_PEAK_TFLOPS if bound == "mfma_bf16" else F32_MFMA_PEAK_TFLOPS), "TFLOP/s"
+            bound = "mfma"
         out.append({"kernel": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
                     "frac": round(ach / peak, 4), "ms": round(ms, 4), "work_per_launch": work, "timing": how})
     return out
@@ -326,7 +349,9 @@ def stream_ceilings(device):
 
 def load_traffic(kernel_name):
     """HBM bytes per launch from the committed rocprofv3 --pmc summary (profiles/), if present."""
-    path = os.path.join(ROOT, "profiles", "traffic_r02.json")
+    path = os.path.join(ROOT, "profiles", "traffic_r03.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "traffic_r02.json")
     try:
         with open(path) as f:
             t = json.load(f)
@@ -425,6 +450,116 @@ def cpu_baseline(p):
     }
 
 
+def _row(name, bound, work, ms, how):
+    return (name, bound, work, ms, how)
+
+
+def extra_rows(p, reps):
+    """Rows "not in the step": the other BASELINE shapes and SURVEY 8(d)'s grid, each with its algorithmic bytes / FLOPs
+    (restated in DESIGN.md 4), timed alone back to back with HIP events on the launch stream."""
+    from wvhash import synth
+    from wvhash.engine import hamming as Hm
+    from wvhash.engine.get_knn import knn_float
+    from wvhash.models import SharedDinoHashing, get_fusion_head
+    from wvhash.models.vit import vit_small_14
+    from wvhash.transforms import swt2d
+    from wvhash import _lib
+    dev, rows, skipped, alone = p.dev, [], [], "not part of the step; timed alone, back to back"
+
+    def add(name, bound, work, fn, nrep, how=alone):
+        """One row; a shape the library refuses is listed under kernels_skipped instead of ending the run."""
+        try:
+            rows.append(_row(name, bound, work, time_stage(fn, nrep), how))
+        except Exception as e:                                   # noqa: BLE001
+            skipped.append(f"{name}: {type(e).__name__}: {str(e)[:200]}")
+    img_bytes = lambda B, out_b=4: B * (3 * H * W + 12 * H * W * out_b)            # noqa: E731  u8 in, 4 bands out
+    with torch.no_grad():
+        # ---- SWT: the wavelets of the studies at level 1 (c0 = haar L1), c1's db2 L3 at smaller batches, bf16 output (c4)
+        for wl, lev in (("haar", 1), ("db4", 1), ("bior4.4", 1)):
+            add(f"wv_swt2d_forward[{wl} L{lev} u8->f32, B={p.Q}] (not in the step)", "hbm", img_bytes(p.Q),
+                lambda: swt2d(p.images, wl, lev, out=p.bands if not p.band_major else None), reps)
+        for B in (64, 256, 1024):
+            if B < p.Q:
+                x, o = p.images[:B], torch.empty((B, 3, 4, H, W), dtype=torch.float32, device=dev)
+                add(f"wv_swt2d_forward[db2 L3 u8->f32, B={B}] (not in the step)", "hbm", img_bytes(B),
+                    lambda: swt2d(x, WAVELET, LEVEL, out=o), reps)
+        ob = torch.empty((p.Q, 3, 4, H, W), dtype=torch.bfloat16, device=dev)
+        add(f"wv_swt2d_forward[db2 L3 u8->bf16 (c4), B={p.Q}] (not in the step)", "hbm", img_bytes(p.Q, 2),
+            lambda: swt2d(p.images, WAVELET, LEVEL, out_dtype=torch.bfloat16, out=ob), reps)
+        del ob
+        # ---- ranking at c0 (VOC: 5,823 queries x 5,717 codes, 16 bit, k = N) and c3 (COCO: 5,000 x 117,218, 128 bit)
+        for tag, Q, N, nbits, lc, pl, ks in (("c0", 5823, 5717, 16, 20, 0.07, (5717,)), ("c3", 5000, 117218, 128, 80, 0.036, (5000, 117218))):
+            ql, rl = synth.multi_hot_labels(Q, lc, pl, 31), synth.multi_hot_labels(N, lc, pl, 32)
+            q, r = synth.structured_codes(ql, nbits, 3, 33), synth.structured_codes(rl, nbits, 3, 34)
+            qp, prep = Hm.pack_codes(q.to(dev)), Hm.PreparedDB(Hm.pack_codes(r.to(dev)), nbits)
+            qlp, rlp = Hm.pack_labels(ql.to(dev)), Hm.pack_labels(rl.to(dev))
+            labels = Hm.PreparedLabels(rlp)
+            lw = rlp.shape[1]
+            for k in ks:
+                kk = "N" if k == N else str(k)
+                code_b = (Q + N) * nbits // 8
+                add(f"wv_hamming_topk[{tag}: {Q} x {N}, {nbits} bit, k={kk}, lists only] (not in the step)", "hbm",
+                    code_b + Q * k * 4, lambda: Hm.hamming_topk(qp, prep, nbits, k, want_dist=False), max(2, reps // 2))
+                fused = Hm.hamming_map_at_k(qp, prep, labels, qlp, nbits, k)
+                if fused is not None:
+                    fn, how = (lambda: Hm.hamming_map_at_k(qp, prep, labels, qlp, nbits, k)), "ranking + AP without lists (wv_hamming_map_at_k)"
+                else:
+                    def fn():
+                        idx = Hm.hamming_topk(qp, prep, nbits, k, want_dist=False)[0]
+                        return Hm.map_at_k(idx, qlp, rlp)
+                    how = "wv_hamming_topk + wv_map_at_k (k beyond the fused kernel)"
+                add(f"mAP@{kk} [{tag}: {Q} x {N}, {nbits} bit; {how}] (not in the step)", "hbm",
+                    code_b + (Q + N) * 8 * lw + Q * 4, fn, max(2, reps // 2))
+            del qp, prep, labels, qlp, rlp
+        # ---- head: B in {256, 4096} x Nq in {1, 4, 8}
+        for nq in (1, 4, 8):
+            head = get_fusion_head({"type": "cross_attention_advanced", "output_dim": EMBED, "num_heads": HEADS, "num_queries": nq,
+                                    "sub_band_dropout_p": 0, "ortho_weight": 0.1}, [EMBED] * 4)
+            head.load_state_dict(synth.head_state(EMBED, nq, "concat", seed=40 + nq))
+            head = head.to(dev).eval()
+            for B in (256, 4096):
+                feats = list(torch.stack(synth.band_features(B, EMBED, seed=50 + nq)).to(dev).unbind(0))
+                # separate launches (small batches) project K too: 14.2 MFLOP at Nq = 4; count what SURVEY 8(a-12) counts
+                flops = 2 * (2 * 4 * EMBED * EMBED + 2 * HEADS * nq * 4 * (EMBED // HEADS) + nq * EMBED * EMBED
+                             + 2 * nq * EMBED * 4 * EMBED + nq * EMBED * EMBED)
+                add(f"wv_band_attn_pool[Nq={nq}, B={B}] (not in the step)", "mfma", B * flops, lambda: head(feats), reps)
+        # ---- float k-NN (get_knn cosine / l2 path of non-hashing models): 2048 x 25,000, D = 384, k = 5000
+        g = torch.Generator().manual_seed(7)
+        qf, rf = torch.randn(p.Q, EMBED, generator=g).to(dev), torch.randn(N_DB, EMBED, generator=g).to(dev)
+        add(f"wv_knn_float[{p.Q} x {N_DB}, D={EMBED}, IP, k={TOPK}: fp32 MFMA scores + radix ranking] (not in the step)",
+            "mfma", 2 * p.Q * N_DB * EMBED, lambda: knn_float(rf, qf, TOPK, _lib.WV_METRIC_IP), max(2, reps // 2))
+        del qf, rf
+        # ---- the pipeline with a consumer (SURVEY 8(d) metric 3, f-1): raw u8 batch -> SWT (bf16, band-major, kernel-written) ->
+        # random-init ViT-S/14 on the 4 x B band images (stock PyTorch, bf16 autocast: the backbone is out of scope but it
+        # READS the sub-bands) -> head -> hash -> packed codes -> ranking + AP.  main/engine/evaluate.py:26-64 is the sweep
+        # it replaces; the reference's evaluate.py sets with_autocast = True.
+        Bm = min(256, p.Q)
+        net = SharedDinoHashing({"name": "dinov2_vits14", "frozen": True},
+                                {"type": "cross_attention_advanced", "output_dim": EMBED, "num_heads": HEADS, "dropout": 0.1,
+                                 "num_queries": NQ, "sub_band_dropout_p": 0.3, "ortho_weight": 0.1}, {"nbits": NBITS},
+                                backbone=vit_small_14()).to(dev).eval()
+        net.set_wavelet(LEVEL, WAVELET)
+        raw, qlab = p.images[:Bm], p.qlab[:Bm]
+
+        def model_step():
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                packed = net.encode_packed(raw)
+            return Hm.hamming_map_at_k(packed, p.db_packed_full, p.lab_prepared or Hm.PreparedLabels(p.dblab), qlab, NBITS, TOPK)
+
+        try:
+            ms = time_stage(model_step, 3)
+            rows.append(_row(f"deferred SharedDinoHashing [raw u8 [{Bm},3,224,224] -> SWT db2 L3 (bf16) -> random-init ViT-S/14 (PyTorch, "
+                             f"bf16 autocast, 4 x {Bm} images) -> head -> hash -> fused mAP@{TOPK}]: {Bm / (ms * 1e-3):.0f} query images/s "
+                             "(not in the step; the backbone dominates and is outside the accelerated path)", "mfma_bf16",
+                             # ViT-S/14 at 224: 257 tokens, 12 blocks of (4 E^2 attention + 8 E^2 MLP) MACs per token, + QK^T / AV
+                             4 * Bm * 2 * (12 * (4 * EMBED * EMBED + 8 * EMBED * EMBED) * 257 + 12 * 2 * 257 * 257 * EMBED), ms,
+                             "3 forward passes after 1 warm-up, HIP events; FLOPs = the ViT's, priced against the dense bf16 MFMA peak"))
+        except Exception as e:                                   # noqa: BLE001
+            skipped.append(f"deferred SharedDinoHashing pipeline: {type(e).__name__}: {str(e)[:200]}")
+        del net
+    return rows, skipped
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
@@ -449,20 +584,64 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def main():
-    args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(self_launch(args))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)   # rehearsal: several ranks on one GPU
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+def timed_steps(p, steps, barrier):
+    """EXACTLY `steps` steps between two barrier + synchronize pairs -> (seconds, last outputs, SWT ms per step (HIP events
+    around the launch in every step), collectives counted during the steps, host synchronisations torch reported)."""
+    from wvhash import parallel
+    barrier()
+    p.needs, p.marks = [], []          # one HIP event before and after the SWT launch of every timed step
+    parallel.TRACE = parallel.ExchangeTrace()
+    staged = p.world > 1 and dist.get_backend() != "nccl"      # gloo rehearsal: the host staging synchronises by design
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        if not staged:
+            torch.cuda.set_sync_debug_mode("warn")              # any host read inside a step shows up as a warning
+        t0 = time.perf_counter()
+        out = None
+        for _ in range(steps):
+            out = p.step()
+        if not staged:
+            torch.cuda.set_sync_debug_mode("default")
+        barrier()
+        elapsed = time.perf_counter() - t0
+    trace, parallel.TRACE = parallel.TRACE, None
+    syncs = None if staged else sum(1 for w in caught if "synchroniz" in str(w.message).lower())
+    marks, p.marks = p.marks, None
+    swt_ms = [a[1].elapsed_time(b[1]) for a, b in zip(marks[0::2], marks[1::2])]
+    return elapsed, out, sum(swt_ms) / max(len(swt_ms), 1), trace, syncs
+
+
+def per_rank_breakdown(p, reps=5):
+    """A few extra steps with HIP events between the stages and around every collective: this rank's milliseconds per step."""
+    from wvhash import parallel
+    for _ in range(3):
+        p.step()
+    torch.cuda.synchronize()
+    parallel.TRACE = parallel.ExchangeTrace(timing=True)
+    p.marks, p.marks_all = [], True
+    for _ in range(reps):
+        p.step()
+    torch.cuda.synchronize()
+    marks, p.marks, p.marks_all = p.marks, None, False
+    trace, parallel.TRACE = parallel.TRACE, None
+    per = len(marks) // reps
+    step_ms = sum(marks[r * per][1].elapsed_time(marks[(r + 1) * per - 1][1]) for r in range(reps)) / reps
+    coll = {k: v / reps for k, v in trace.ms().items()}
+    stages = {}
+    for r in range(reps):
+        m = marks[r * per:(r + 1) * per]
+        for (_, e0), (name, e1) in zip(m[:-1], m[1:]):
+            stages[name] = stages.get(name, 0.0) + e0.elapsed_time(e1) / reps
+    return {"rank": p.rank, "step_ms": round(step_ms, 4), "collectives_ms": {k: round(v, 4) for k, v in coll.items() if v},
+            "kernels_ms": round(step_ms - sum(coll.values()), 4),
+            "stage_ms": {"swt": round(stages.get("swt1", 0.0), 4), "head": round(stages.get("head1", 0.0), 4),
+                         "hash_tail": round(stages.get("tail1", 0.0), 4),
+                         "search (kernels + collectives)": round(stages.get("rankmap1", stages.get("rank1", 0.0) + stages.get("map1", 0.0)), 4)},
+            "bytes_sent_per_step": {k: v // reps for k, v in trace.bytes.items() if v}}
+
+
+def run(args, rank, world, device):
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("WV_DIST_BACKEND", "nccl")   # "gloo": single-GPU rehearsal of the N>1 path
@@ -470,44 +649,68 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-
-    p = Pipeline(args.queries, rank, world, device, streams=args.streams)
+    cdev = device if (world == 1 or backend == "nccl") else torch.device("cpu")   # where small control tensors live
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- setup; a rank that fails here tells the others instead of leaving them in their first collective
+    p, setup_error = None, None
+    try:
+        p = Pipeline(args.queries, rank, world, device, streams=args.streams)
+    except Exception as e:                                   # noqa: BLE001
+        setup_error = e
+        print(f"[bench rank {rank}] setup failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+    if world > 1:
+        bad = torch.tensor([1 if setup_error is not None else 0], dtype=torch.int32, device=cdev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()):
+            if setup_error is None:
+                print(f"[bench rank {rank}] another rank failed during setup; exiting", file=sys.stderr, flush=True)
+            raise SystemExit(1)
+    elif setup_error is not None:
+        raise setup_error
+
     out = p.step()                     # untimed: sizes the list exchange exactly (one host read), compiles nothing
     p.learn_send_hint()
+    first = None
+    if world == 1:
+        # ---- as allocated, clocks as they are: W warm-up steps, K timed steps -- before the two setup steps below
+        for _ in range(args.warmup):
+            p.step()
+        e_first, _, swt_first, _, _ = timed_steps(p, args.steps, barrier)
+        first = {"value": round(args.queries * args.steps / e_first, 1), "ms_per_step": round(e_first / args.steps * 1e3, 4),
+                 "swt_ms": round(swt_first, 4)}
+    p.tune_placement()                 # setup: fastest of several candidate allocations of the sub-band buffer
     for _ in range(args.clock_steps):  # bring the clocks up (reported in config.clock_steps)
         p.step()
     for _ in range(args.warmup):
         out = p.step()
-    barrier()
-    p.needs = []
-    p.marks = []                       # one HIP event before and after the SWT launch of every timed step
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = p.step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    swt_marks, p.marks = p.marks, None
+    elapsed, out, swt_ms_live, trace, host_syncs = timed_steps(p, args.steps, barrier)
     exchange = None
     if world > 1:
         from wvhash.parallel import exchange_ok
-        bad = torch.tensor([0 if exchange_ok(p.needs, p.send_hint, p.kin) else 1], dtype=torch.int32,
-                           device=device if dist.get_backend() == "nccl" else "cpu")
+        per_step = {k: v / args.steps for k, v in trace.calls.items()}
+        bad = torch.tensor([0 if exchange_ok(p.needs, p.send_hint, p.kin) else 1,
+                            0 if per_step == {"all_gather": 1.0, "all_to_all": 1.0, "all_reduce": 0.0} else 1],
+                           dtype=torch.int32, device=cdev)
         dist.all_reduce(bad, op=dist.ReduceOp.MAX)             # every rank learns whether any rank fell short
-        ok = int(bad.item()) == 0
-        exchange = {"prefix_entries": p.send_hint, "max_possible": p.kin, "verified_exact": ok}
+        ok, lean = int(bad[0].item()) == 0, int(bad[1].item()) == 0
+        mine = per_rank_breakdown(p)
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+        exchange = {"prefix_entries": p.send_hint, "max_possible": p.kin, "verified_exact": ok,
+                    "collectives_per_timed_step": {k: v for k, v in per_step.items()},
+                    "one_all_gather_one_all_to_all_per_step": lean,
+                    "bytes_sent_per_rank_per_timed_step": {k: v // args.steps for k, v in trace.bytes.items() if v},
+                    "host_syncs_in_timed_steps": host_syncs,
+                    "per_rank": ranks}
         if not ok:
             raise SystemExit(f"a timed step needed a longer list prefix than the hinted {p.send_hint}: the results of "
                              "that step are not exact, refusing to report a number")
-    swt_ms = [a[1].elapsed_time(b[1]) for a, b in zip(swt_marks[0::2], swt_marks[1::2])]
-    swt_ms_live = sum(swt_ms) / max(len(swt_ms), 1)
     ap = out[3]
-    cdev = device if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")
     t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     ap_sum = ap.double().sum().reshape(1).to(cdev)
     if world > 1:
@@ -537,6 +740,7 @@ def main():
             "streams": args.streams,
             "clock_steps": args.clock_steps,   # untimed steps before the warm-up steps (GPU clock ramp after idle)
             "swt_output_placement": p.placement,  # setup: fastest of several candidate allocations of the sub-band buffer
+            "host_syncs_in_timed_steps": host_syncs,
             "backend": (("rccl" if dist.get_backend() == "nccl" else
                          f"{dist.get_backend()} (REHEARSAL: {world} ranks share {torch.cuda.device_count()} GPU(s), "
                          "collectives staged through host memory)") if world > 1 else "none"),
@@ -546,6 +750,13 @@ def main():
                             "(first step: lists, to size the prefix)") if world > 1 else "single GPU",
         },
     }
+    if first is not None:
+        # the same K steps before the two setup steps that lift `value` (placement probe, clock-ramp steps): what a caller
+        # who allocates once and starts cold measures
+        result["value_first_allocation"] = first["value"]
+        result["first_allocation"] = {"ms_per_step": first["ms_per_step"], "swt_ms": first["swt_ms"],
+                                      "what": f"{args.warmup} warm-up + {args.steps} timed steps on the sub-band buffer as first "
+                                              "allocated, no clock-ramp steps; run before the tuned measurement"}
     if rank == 0 and world == 1:
         kt = kernel_table(p, args.kernel_reps, swt_ms_live)
         dom = max((k for k in kt if "not in the step" not in k["kernel"] and not k["kernel"].startswith("wv_hamming_dist")),
@@ -555,14 +766,52 @@ def main():
                               "traffic": load_traffic(dom["kernel"]),
                               "traffic_source": "rocprofv3 --pmc passes committed under profiles/ (not measured in this run)"}
         result["roofline"].update(stream_ceilings(device))
+        if not args.no_grid:
+            grid, skipped = extra_rows(p, args.kernel_reps)
+            kt += finish_rows(grid)
+            if skipped:
+                result["kernels_skipped"] = skipped
         result["kernels"] = kt
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(p)
     if world > 1:
         dist.barrier()
-        dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)   # rehearsal: several ranks on one GPU
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    code = 0
+    try:
+        run(args, rank, world, device)
+    except SystemExit as e:
+        code = e.code if isinstance(e.code, int) else 1
+        if not isinstance(e.code, int) and e.code is not None:
+            print(f"[bench rank {rank}] {e.code}", file=sys.stderr, flush=True)
+    except BaseException:                                        # noqa: BLE001
+        code = 1
+        print(f"[bench rank {rank}] FAILED:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
+    if world > 1 and code != 0:
+        # Leave at once: the other ranks may sit in a collective this rank will never join, and tearing the process group
+        # down would wait for them.  torch.distributed.run ends the whole group when one rank exits non-zero.
+        sys.stdout.flush()
+        os._exit(code)
+    if world > 1 and dist.is_initialized():
+        dist.destroy_process_group()
+    raise SystemExit(code)
 
 
 if __name__ == "__main__":

@@ -31,22 +31,68 @@ def _cpu_staged(group):
     return dist.get_backend(group) == "gloo"
 
 
+class ExchangeTrace:
+    """What the sharded search puts on the wire: every collective of this module is counted (calls, payload bytes of this
+    rank) and, with timing=True, bracketed by HIP events on the calling stream (the collective's own stream is joined to it
+    by torch before the call returns, so the pair spans queueing + transfer).  Install with `parallel.TRACE = ExchangeTrace()`;
+    bench.py asserts one all_gather + one all_to_all per steady-state step with it and reports per-rank milliseconds."""
+
+    def __init__(self, timing=False):
+        self.timing = timing
+        self.calls = {"all_gather": 0, "all_to_all": 0, "all_reduce": 0}
+        self.bytes = {"all_gather": 0, "all_to_all": 0, "all_reduce": 0}
+        self.events = []                                  # (name, start, end)
+
+    def ms(self):
+        out = {"all_gather": 0.0, "all_to_all": 0.0, "all_reduce": 0.0}
+        for name, e0, e1 in self.events:
+            out[name] += e0.elapsed_time(e1)
+        return out
+
+
+TRACE = None
+
+
+class _traced:
+    def __init__(self, name, t):
+        self.name, self.t, self.e0 = name, t, None
+
+    def __enter__(self):
+        tr = TRACE
+        if tr is not None:
+            tr.calls[self.name] += 1
+            tr.bytes[self.name] += self.t.numel() * self.t.element_size()
+            if tr.timing and self.t.is_cuda:
+                self.e0 = torch.cuda.Event(enable_timing=True)
+                self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.e0 is not None and TRACE is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            TRACE.events.append((self.name, self.e0, e1))
+        return False
+
+
 def _all_gather(out, inp, group):
-    if _cpu_staged(group) and inp.is_cuda:
-        o, i = out.cpu(), inp.cpu()
-        dist.all_gather_into_tensor(o, i, group=group)
-        out.copy_(o)
-    else:
-        dist.all_gather_into_tensor(out, inp, group=group)
+    with _traced("all_gather", inp):
+        if _cpu_staged(group) and inp.is_cuda:
+            o, i = out.cpu(), inp.cpu()
+            dist.all_gather_into_tensor(o, i, group=group)
+            out.copy_(o)
+        else:
+            dist.all_gather_into_tensor(out, inp, group=group)
 
 
 def _all_to_all(out, inp, group):
-    if _cpu_staged(group) and inp.is_cuda:
-        o, i = out.cpu(), inp.cpu()
-        dist.all_to_all_single(o, i, group=group)
-        out.copy_(o)
-    else:
-        dist.all_to_all_single(out, inp, group=group)
+    with _traced("all_to_all", inp):
+        if _cpu_staged(group) and inp.is_cuda:
+            o, i = out.cpu(), inp.cpu()
+            dist.all_to_all_single(o, i, group=group)
+            out.copy_(o)
+        else:
+            dist.all_to_all_single(out, inp, group=group)
 
 
 def pad_value(nbits):
@@ -55,12 +101,13 @@ def pad_value(nbits):
 
 
 def _all_reduce(t, op, group):
-    if _cpu_staged(group) and t.is_cuda:
-        c = t.cpu()
-        dist.all_reduce(c, op=op, group=group)
-        t.copy_(c)
-    else:
-        dist.all_reduce(t, op=op, group=group)
+    with _traced("all_reduce", t):
+        if _cpu_staged(group) and t.is_cuda:
+            c = t.cpu()
+            dist.all_reduce(c, op=op, group=group)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=op, group=group)
 
 
 def sharded_hamming_topk(q_local, db_shard, nbits, k, n_total, group=None, workspace=None, trim=True,

@@ -83,19 +83,22 @@ def swt2d(x, wavelet="haar", level=1, channels_last=False, out_dtype=torch.float
 
 
 def swt2d_place_output(x, wavelet="haar", level=1, channels_last=False, out_dtype=torch.float32, band_major=False,
-                       candidates=8, launches=4):
+                       candidates=8, launches=4, first=None):
     """A result buffer for swt2d(x, ..., out=buffer) placed where the kernel runs fastest, for callers that keep one buffer
     for many batches of x's shape (a serving loop, bench.py).  WHERE a multi-GB write target lies in HBM moves the kernel by
     about +-3 % (the first large allocation of a process up to +10 %; one allocation behaves the same at every offset inside
     it -- DESIGN.md 5), so `candidates` buffers are allocated side by side, the transform is timed on each (`launches`
     launches, HIP events on the current stream) and the fastest is returned; the others go back to the driver.
+    `first`: a buffer of the right shape the caller already holds; it is candidate 0.
     -> (buffer, {"candidates", "probe_ms", "picked"})."""
     _lib.require_gpu()
     layout, B, C, H, W = _layout_and_shape(x.contiguous(), channels_last)
     shape = (4, B, C, H, W) if band_major else (B, C, 4, H, W)
+    if first is not None and (tuple(first.shape) != shape or first.dtype != out_dtype or first.device != x.device):
+        raise ValueError("swt2d_place_output: `first` does not have the output's shape / dtype / device")
     bufs, ms = [], []
-    for _ in range(max(1, int(candidates))):
-        buf = torch.empty(shape, dtype=out_dtype, device=x.device)
+    for c in range(max(1, int(candidates))):
+        buf = first if (c == 0 and first is not None) else torch.empty(shape, dtype=out_dtype, device=x.device)
         bufs.append(buf)
         if candidates <= 1 or B == 0:
             break

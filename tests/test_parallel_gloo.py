@@ -194,8 +194,12 @@ def _map_worker(rank, world, port, cases, nbits, ql, out_dir, lc=12, p=0.2):
         lo, hi, per = parallel.shard_bounds(n_db, world, rank)
         sl = slice(rank * ql, (rank + 1) * ql)
         for hint in (min(k, per), 1, None):            # None: the exchange is sized exactly first (histograms, two all-reduces)
+            parallel.TRACE = parallel.ExchangeTrace()
             ap, nrel, need = parallel.sharded_hamming_map_at_k(_pack(q_all[sl]), _label_words(ql_all[sl]), _pack(r[lo:hi]),
                                                                _label_words(rl[lo:hi]), nbits, k, n_db, hint)
+            calls, parallel.TRACE = parallel.TRACE.calls, None
+            # a hinted (steady-state) call: ONE all_gather (codes + label words) and ONE all_to_all, nothing else
+            assert calls == {"all_gather": 1, "all_to_all": 1, "all_reduce": 0 if hint is not None else 2}, calls
             out[(n_db, k, hint)] = (ap, nrel, need, max(1, min(min(k, per), hint)) if hint is not None else min(k, per))
     torch.save(out, os.path.join(out_dir, f"m{rank}.pt"))
     dist.barrier()
@@ -205,7 +209,9 @@ def _map_worker(rank, world, port, cases, nbits, ql, out_dir, lc=12, p=0.2):
 @pytest.mark.parametrize("world,cases,nbits,lc,p", [
     (2, [(1000, 300), (1001, 600), (64, 10)], 64, 12, 0.2), (3, [(500, 500), (77, 40)], 64, 12, 0.2),
     # the c3 shape class: 128-bit codes and COCO's 80 classes = TWO label words per row next to two code words
-    (2, [(1000, 300), (1001, 600)], 128, 80, 0.036), (3, [(500, 500), (77, 40)], 128, 80, 0.036)])
+    (2, [(1000, 300), (1001, 600)], 128, 80, 0.036), (3, [(500, 500), (77, 40)], 128, 80, 0.036),
+    # the world size of the driver's scaling run (8 ranks; ragged last shard): the exchange the first RCCL run will make
+    (8, [(1001, 300)], 64, 38, 0.1)])
 def test_sharded_map_exchange_of_relevance_strings(tmp_path, world, cases, nbits, lc, p):
     """The exchange behind sharded_hamming_map_at_k (codes + label words in one all_gather, relevance strings + histograms
     through one all_to_all, merge on the receiving rank) with CPU stand-ins for the two kernels: AP and hit counts of the
