@@ -155,7 +155,11 @@ __device__ __forceinline__ void rank2_distances(const uint4 *__restrict__ img, c
 #pragma unroll
             for (int u = 0; u < LPB; ++u)                        // uniform row base (SGPRs) + the lane's 32-bit byte offset
                 raw[u] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(img) +
+#ifdef WV_R2_SAMEROW   /* timing probe: every load hits the same 4 KB of the image (L1-resident) */
+                                                          (size_t)min((bi * LPB + u) & 1, rows - 1) * (TPQ * 16) + toff);
+#else
                                                           (size_t)min(bi * LPB + u, rows - 1) * (TPQ * 16) + toff);
+#endif
 #pragma unroll
             for (int qq = 0; qq < QB; ++qq) {
 #pragma unroll
@@ -453,7 +457,7 @@ __device__ __forceinline__ void rank2_dist_row(const Rank2Lds &L, int nbins, int
 // zeroing overlaps the distance pass).  Ends with a group barrier.
 // NC = distance-cache words (4 items each): items per thread C <= 4 * NC
 template <int TPQ, int NC, bool AP = false>
-__device__ __forceinline__ void rank2_rank(uint32_t (&dc)[NC], uint32_t dmin, int64_t N, int C, int nbins, int k,
+__device__ __forceinline__ void rank2_rank(const uint32_t (&dc)[NC], uint32_t dmin, int64_t N, int C, int nbins, int k,
                                            uint32_t *__restrict__ cum_out, uint8_t *__restrict__ dist_out, uint8_t *lds_raw, int t,
                                            const uint32_t *__restrict__ cls = nullptr, uint64_t qlabel = 0, uint64_t qlabel_hi = 0,
                                            float *__restrict__ ap_out = nullptr, int32_t *__restrict__ nrel_out = nullptr,
@@ -492,28 +496,18 @@ __device__ __forceinline__ void rank2_rank(uint32_t (&dc)[NC], uint32_t dmin, in
     char *stage_b = reinterpret_cast<char *>(L.stage);
     const uint32_t trash = 2u * (uint32_t)(k + t);
     const uint32_t k2 = 2u * (uint32_t)k;
-    bool first_window = true;
 
     R2_STAMP(0);
     for (;;) {
         const bool place = placed < (uint32_t)k;                 // uniform: false = count-only pass (cum requested)
-        // ---- count: one LDS add per item, into the row of its bin or into the dummy row.  Batches of 8 items (two
-        // cache words): one uniform branch per batch; the adds return nothing, so they simply queue up.
-        // The row is addressed by the ABSOLUTE distance, clamped from above only (min straight from the cache byte, one
-        // shift-add: 2 VALU instructions per item instead of subtract, clamp, shift-add): in the first window no row lies
-        // below `lo` (it starts at the query's smallest distance); before a later window the cache bytes below it are set
-        // to 255 once (rare: the k-th neighbour of a hashing query lies inside the first 32 bins).
-        if (!first_window) {
-#pragma unroll
-            for (int i = 0; i < NC; ++i) {
-                uint32_t w = dc[i], m = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) m |= (((w >> (8 * j)) & 0xffu) < (uint32_t)lo ? 0xffu : 0u) << (8 * j);
-                dc[i] = w | m;
-            }
-        }
-        const uint32_t hi_bin = (uint32_t)(lo + kWinBins);       // first bin beyond the window = the dummy row
-        char *row0 = tbl + (int)cell_addr - lo * ROWB;           // row of absolute bin b: row0 + b * ROWB
+        // ---- count: one LDS add per item, into the row of its bin or into the dummy row (items below the window --
+        // placed by an earlier one -- wrap to huge values and clamp to the dummy row too).  Batches of 8 items (two cache
+        // words): one uniform branch per batch; the adds return nothing, so they simply queue up.
+        // (Addressing the row by the ABSOLUTE distance, clamped from above only -- 2 VALU instructions per item instead of
+        // 3 -- was built in round 3: it needs the cache bytes below a later window rewritten to 255, and that rarely taken
+        // path cost registers (28-64 bytes of scratch per thread) for no measurable gain: the item loops are not what bounds
+        // the launch)
+        char *row0 = tbl + cell_addr;
 #pragma unroll
         for (int bw = 0; bw < NC; bw += 2) {
             if (bw * 4 < C && (WV_R2_ABL < 3 || WV_R2_ABL == 5 || k < 0)) {         // uniform; items >= C of the batch hold 255 -> dummy row
@@ -521,7 +515,7 @@ __device__ __forceinline__ void rank2_rank(uint32_t (&dc)[NC], uint32_t dmin, in
                 for (int j = 0; j < 8; ++j) {
                     if (bw + (j >> 2) < NC) {
                         const uint32_t d = (dc[bw + (j >> 2)] >> (8 * (j & 3))) & 0xffu;
-                        const uint32_t b = min(d, hi_bin);
+                        const uint32_t b = min(d - (uint32_t)lo, (uint32_t)kWinBins);
                         __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(row0 + b * ROWB), cell_inc,
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
@@ -610,7 +604,7 @@ __device__ __forceinline__ void rank2_rank(uint32_t (&dc)[NC], uint32_t dmin, in
                         old[j] = 0;
                         if (bw + (j >> 2) < NC) {
                             const uint32_t d = (dc[bw + (j >> 2)] >> (8 * (j & 3))) & 0xffu;
-                            const uint32_t b = min(d, hi_bin);
+                            const uint32_t b = min(d - (uint32_t)lo, (uint32_t)kWinBins);
                             old[j] = __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(row0 + b * ROWB), cell_inc,
                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
@@ -630,7 +624,6 @@ __device__ __forceinline__ void rank2_rank(uint32_t (&dc)[NC], uint32_t dmin, in
         R2_STAMP(3);
         placed += win_total;
         lo += kWinBins;
-        first_window = false;
         // uniform exit: the list is complete and nobody asked for the full histogram, or no bins are left
         if (lo >= nbins || (placed >= (uint32_t)k && !cum_out)) break;
         group_sync<TPQ>();                                        // every add of this window has returned

@@ -156,6 +156,54 @@ def bucket_sets(indices_row, dist_row):
 
 
 # ----------------------------------------------------------------------------- map_level0
+def map_tie_bounds(dist, gnd, k):
+    """[lowest, highest] mAP@k any ordering can give that sorts by distance and breaks ties arbitrarily -- what separates
+    the reference's `torch.argsort(hamm)` (unstable: the order inside a distance bucket is implementation-defined,
+    accuracy_calculator.py:220) from the canonical (distance, index) order.  dist: integer distances [Q, N]; gnd: bool
+    relevance [Q, N].  Inside a complete bucket the hits' precision terms are largest with the relevant rows first and
+    smallest with them last (the hit counts at the bucket's borders are fixed); for the bucket the cut at k falls into,
+    every possible number of relevant rows among the kept ones is tried (leaving a late hit out can RAISE the mean)."""
+    import numpy as np
+    dist, gnd = np.asarray(dist).astype(np.int64), np.asarray(gnd).astype(bool)
+    Q, N = dist.shape
+    k = N if k is None else min(int(k), N)
+    lo_sum = hi_sum = 0.0
+
+    def terms(start_rank, hits_before, n_rel, n_slots, first):
+        """sum of j / rank over n_rel hits placed at the first / last of n_slots consecutive ranks (1-based start_rank)"""
+        ranks = np.arange(n_rel) + (start_rank if first else start_rank + n_slots - n_rel)
+        return float(((hits_before + 1 + np.arange(n_rel)) / ranks.astype(np.float64)).sum())
+
+    for i in range(Q):
+        lo_opts, hi_opts = [(0.0, 0)], [(0.0, 0)]               # (sum of terms, hits) reachable so far: min / max tracks
+        pos, hits = 0, 0
+        s_lo = s_hi = 0.0
+        for b in np.unique(dist[i]):
+            m = dist[i] == b
+            size, rel = int(m.sum()), int((m & gnd[i]).sum())
+            if pos + size <= k:                                   # complete bucket
+                s_hi += terms(pos + 1, hits, rel, size, True)
+                s_lo += terms(pos + 1, hits, rel, size, False)
+                pos, hits = pos + size, hits + rel
+                if pos == k:
+                    lo_opts, hi_opts = [(s_lo, hits)], [(s_hi, hits)]
+                    break
+            else:                                                 # the cut at k: `slots` of the bucket's rows are kept
+                slots = k - pos
+                cand_lo, cand_hi = [], []
+                for h in range(max(0, slots - (size - rel)), min(rel, slots) + 1):
+                    cand_hi.append((s_hi + terms(pos + 1, hits, h, slots, True), hits + h))
+                    cand_lo.append((s_lo + terms(pos + 1, hits, h, slots, False), hits + h))
+                lo_opts, hi_opts = cand_lo, cand_hi
+                break
+        else:
+            lo_opts, hi_opts = [(s_lo, hits)], [(s_hi, hits)]
+        ap = lambda sh: sh[0] / sh[1] if sh[1] else 0.0          # noqa: E731
+        lo_sum += min(ap(x) for x in lo_opts)
+        hi_sum += max(ap(x) for x in hi_opts)
+    return lo_sum / Q, hi_sum / Q
+
+
 def retrieval_map(knn_scores, relevances, not_lone_query_mask=None):
     """torchmetrics RetrievalMAP over (preds, target, indexes) as built at
     accuracy_calculator.py:156-167: per query AP over its k retrieved items ordered by

@@ -378,10 +378,18 @@ def test_hip_path_against_reference_executed_outputs(gold):
             un = order[i][:k]
             assert torch.equal(di[i][un], dk[i].cpu().long())
             assert ranking.bucket_sets(un, di[i][un]) == ranking.bucket_sets(idx[i].cpu().long(), dk[i].cpu().long())
-        # the reported metric: tie noise only (exact on the tie-free case below)
+        # the reported metric.  The tight chain is: HIP == oracle's canonical (stable) value to 1e-6 (here), and the
+        # oracle with the reference's recorded order == the reference's value (asserted at generation time and in
+        # tests/test_oracle_ranking.py).  Between the canonical order and the reference's unstable argsort lies tie noise
+        # only, bounded PER CASE: both values must fall inside the interval of mAPs that orderings differing only inside
+        # distance buckets can produce (oracle/ranking.map_tie_bounds; degenerate -- a point -- on the tie-free case).
         m = calc.calculate_maphashing(q, ql, r, rl, k)
         m_all = calc.calculate_maphashing(q, ql, r, rl, None)
-        assert abs(m - gold[n + "/ref_map"][0]) < 0.05 and abs(m_all - gold[n + "/ref_map_all"][0]) < 0.05
+        assert abs(m - float(gold[n + "/map_stable"][0])) < 1e-6
+        for mine, kk, key in ((m, k, "ref_map"), (m_all, None, "ref_map_all")):
+            lo, hi = ranking.map_tie_bounds(gold[n + "/ref_dist"].round(), gold[n + "/ref_gnd"], kk)
+            ref = float(gold[f"{n}/{key}"][0])
+            assert lo - 1e-6 <= mine <= hi + 1e-6 and lo - 1e-6 <= ref <= hi + 1e-6, (n, kk, lo, mine, ref, hi)
         assert abs(calc.calculate_bit_balance(r) - gold[n + "/ref_bit_balance"][0]) < 1e-6
         assert abs(calc.calculate_worst_bit_balance(r) - gold[n + "/ref_bit_balance"][1]) < 1e-6
         # get_knn, both source modes: the reference's inner products exactly, its index sets per complete bucket

@@ -171,3 +171,18 @@ def test_label_comparison_other_branches_match_reference(gold):
     ql3 = torch.from_numpy(gold["mixed/ql"].astype(np.float32))
     knn = torch.from_numpy(gold["mixed/knn_labels"].astype(np.float32))
     np.testing.assert_array_equal(ranking.label_comparison_fn(ql3[:, None], knn).numpy(), gold["mixed/ref_gnd"])
+
+
+def test_reference_map_lies_inside_the_tie_bounds_of_its_own_distances(gold):
+    """The only freedom between the reference's unstable argsort and the canonical order is the order inside distance
+    buckets; map_tie_bounds gives the exact interval of mAP@k that freedom spans.  The reference-executed values and the
+    canonical ones lie inside it for every fixture, and the interval is a point where no ties exist."""
+    for n in ["rand_q5_n64_b16", "rand_q16_n500_b32", "struct_q12_n1000_b64", "struct_q8_n777_b128", "tiefree_q8_n60_b128"]:
+        k = int(gold[f"{n}/k"][0])
+        for kk, key in ((k, "ref_map"), (None, "ref_map_all")):
+            lo, hi = ranking.map_tie_bounds(gold[f"{n}/ref_dist"].round(), gold[f"{n}/ref_gnd"], kk)
+            assert lo - 1e-6 <= float(gold[f"{n}/{key}"][0]) <= hi + 1e-6      # (the reference sums fp32 quotients)
+        lo, hi = ranking.map_tie_bounds(gold[f"{n}/ref_dist"].round(), gold[f"{n}/ref_gnd"], k)
+        assert lo - 1e-6 <= float(gold[f"{n}/map_stable"][0]) <= hi + 1e-6
+        if n.startswith("tiefree"):
+            assert hi - lo < 1e-12
