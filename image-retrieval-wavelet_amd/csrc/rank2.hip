@@ -698,7 +698,7 @@ int rank2_labels_prepare(const uint64_t *dblab, void *cls, int64_t N, int lwords
 }
 
 // minimum waves per SIMD the register allocation has to leave room for (the LDS footprint admits at least as many)
-constexpr int rank2_min_waves(int nc, int qb) { return nc * qb <= 8 ? 7 : (nc * qb <= 16 ? 6 : (nc * qb <= 25 ? WV_R2_W25 : (nc * qb <= 32 ? 4 : 3))); }
+constexpr int rank2_min_waves(int nc, int qb) { return nc * qb <= 8 ? 7 : (nc * qb <= 16 ? 6 : (nc * qb <= 25 ? WV_R2_W25 : (nc * qb <= 50 ? 4 : 3))); }
 
 // AP = true: the instantiation behind wv_hamming_map_at_k (its own kernels: the plain ranking keeps its registers)
 //
@@ -834,11 +834,12 @@ static int launch_rank2_nc(const uint64_t *q, const void *img, int32_t *idx, uin
                            int C, int nbins, int k, int64_t idx_offset, uint32_t *cum, const Rank2Ap &apx, hipStream_t st)
 {
     // Sharing one pass over the image between QBMAX queries of a group (ranked one after the other) was measured on
-    // MI355X twice (round 2: c1 66 vs 50 us; round 3, with the distance pass known to be half of the launch -- 20.9 of
-    // 43.7 us with everything after it removed -- and the leaner item loops: 62-64 vs 43-45 us, histogram-only launches 33 vs
-    // 22 us): two distance caches take 168 VGPRs (3 waves per SIMD instead of 5), and what the distance pass needs is
-    // bytes in flight -- it runs at 23 TB/s of L2 -> L1 traffic chip-wide, two thirds of the L2's peak, with a queueing
-    // latency of ~2 us per load -- not fewer loads.  The kernel keeps the template parameter; only QB = 1 is instantiated.
+    // MI355X three times: round 2 (c1: 66 vs 50 us); round 3 with the distance pass known to be 45 % of the launch (19.6 of
+    // 43.7 us with everything after it removed) and the leaner item loops, at 168 VGPRs / 3 waves per SIMD: 62-64 vs 43-45 us,
+    // histogram-only launches 33 vs 22 us; and capped at 128 VGPRs / 4 waves per SIMD (8 queries resident per CU instead of 5):
+    // lists 47.2-47.6 vs 44.2-45.9 us, ranking + AP 63-65 vs 59.4-59.9, histogram-only 22.3 vs 22.6 -- half the loads in the
+    // same time.  What the distance pass needs is bytes in flight (latency x concurrency), not fewer loads.  The kernel keeps
+    // the template parameter; only QB = 1 is instantiated.
     (void)QBMAX;
     return launch_rank2_qb<WORDS, TPQ, NC, 1>(q, img, idx, rows16, dist, Q, N, C, nbins, k, idx_offset, cum, apx, st);
 }
