@@ -543,6 +543,10 @@ __global__ __launch_bounds__(2 * NH, MINW) void k_swt_slide(const InT *__restric
     }
 }
 
+// Round 3, measured and removed: pulling a workgroup's NEXT plane into L2 in one burst at the start of each plane (one dword per
+// 128-byte line, so that HBM sees one 50 KB read per plane instead of fifteen 3.5 KB reads mixed into the write stream):
+// 1.126-1.130 ms against 1.062 ms back to back (the write stream evicts the lines before they are used: the reads happen
+// twice).  LDS ring pitch W + {0, 4, 8, 12, 28}: no difference (profiles/r03_swt_experiments.txt).
 // Decoupled roles were built and measured in round 2 (per-stage LDS ready / free counters instead of the chunk barrier:
 // 4 stages x 8 rows with producer wave pairs alternating stages, and 2 stages x 16 rows with the stage released as soon as
 // the consumers hold its rows in registers): bit-identical output, 1.22 ms and 1.16 ms against 1.08 ms for this kernel
