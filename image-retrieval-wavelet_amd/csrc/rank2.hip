@@ -138,6 +138,11 @@ __device__ __forceinline__ void rank2_distances(const uint4 *__restrict__ img, c
 {
     constexpr int UNR = WORDS == 1 ? 16 : 8;                     // items per batch: eight 16-byte loads in flight per lane (a
     constexpr int LPB = WORDS == 1 ? UNR / 2 : UNR;              // workgroup's time is a chain of load -> popcount rounds)
+    // (Round 3: a rolling ring -- consume a row, refill its slot with the row 8 further on, so that eight loads stay in flight
+    // for the whole pass instead of draining to zero after every batch -- was built.  Any branch between a refill and its use
+    // lets the compiler sink the load into the branch or wait vmcnt(0) at the join; the branch-free form, pinned with
+    // sched_barrier, ran the distance pass in 55 us against 19.5 us for these batches (ring of 12: 57 us): eight loads per
+    // round trip either way, and the batches issue theirs back to back.  What would help is a deeper ring, i.e. registers.)
     const int first = t * C;
     const int nvalid = min(C, max(0, (int)N - first));           // N < 65536, first <= 256 * 128: plain ints
     const int rows = WORDS == 1 ? (C + 1) / 2 : C;               // image rows
