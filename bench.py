@@ -698,10 +698,18 @@ def run(args, rank, world, device):
                            dtype=torch.int32, device=cdev)
         dist.all_reduce(bad, op=dist.ReduceOp.MAX)             # every rank learns whether any rank fell short
         ok, lean = int(bad[0].item()) == 0, int(bad[1].item()) == 0
+        # the sharded result of the last timed step against the unsharded kernel on THIS rank's queries and the whole
+        # database (every rank holds it: 200 KB): the exchange over the real fabric must reproduce it bit for bit
+        with torch.no_grad():
+            ref = p.Hm.hamming_map_at_k(out[1], p.db_packed_full, p.Hm.PreparedLabels(p.dblab), p.qlab, NBITS, TOPK)
+        same = torch.tensor([0 if (ref is not None and torch.equal(ref[0], out[3])) else 1], dtype=torch.int32, device=cdev)
+        dist.all_reduce(same, op=dist.ReduceOp.MAX)
+        matches = int(same.item()) == 0
         mine = per_rank_breakdown(p)
         ranks = [None] * world
         dist.all_gather_object(ranks, mine)
         exchange = {"prefix_entries": p.send_hint, "max_possible": p.kin, "verified_exact": ok,
+                    "ap_equals_unsharded_kernel_on_every_rank": matches,
                     "collectives_per_timed_step": {k: v for k, v in per_step.items()},
                     "one_all_gather_one_all_to_all_per_step": lean,
                     "bytes_sent_per_rank_per_timed_step": {k: v // args.steps for k, v in trace.bytes.items() if v},
@@ -710,6 +718,9 @@ def run(args, rank, world, device):
         if not ok:
             raise SystemExit(f"a timed step needed a longer list prefix than the hinted {p.send_hint}: the results of "
                              "that step are not exact, refusing to report a number")
+        if not matches:
+            raise SystemExit("the sharded search's average precisions differ from the unsharded kernel's on the same queries: "
+                             "refusing to report a number")
     ap = out[3]
     t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     ap_sum = ap.double().sum().reshape(1).to(cdev)

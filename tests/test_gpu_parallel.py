@@ -138,6 +138,7 @@ def test_bench_launches_its_own_ranks(tmp_path, gpus):
     assert ex["verified_exact"] is True
     assert ex["collectives_per_timed_step"] == {"all_gather": 1.0, "all_to_all": 1.0, "all_reduce": 0.0}
     assert ex["one_all_gather_one_all_to_all_per_step"] is True and ex["prefix_entries"] >= 1
+    assert ex["ap_equals_unsharded_kernel_on_every_rank"] is True
     assert [r["rank"] for r in ex["per_rank"]] == list(range(gpus))
     for r in ex["per_rank"]:
         assert r["step_ms"] > 0 and r["kernels_ms"] > 0 and set(r["collectives_ms"]) <= {"all_gather", "all_to_all"}
