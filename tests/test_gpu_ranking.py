@@ -729,3 +729,17 @@ def test_host_rank_twins_equal_the_kernels(Q, N, nbits, k, lc):
     m_gpu = CustomCalculator(k=k, distance_metric="hamming", with_faiss=False).calculate_maphashing(q, ql, r, rl, k)
     m_cpu = CustomCalculator(k=k, device="cpu", distance_metric="hamming", with_faiss=False).calculate_maphashing(q, ql, r, rl, k)
     assert abs(m_gpu - m_cpu) < 1e-9
+
+
+@pytest.mark.parametrize("k", [32639, 32640, 32768])
+def test_list_length_at_the_windowed_kernels_limit(k):
+    """The windowed kernel counts list positions in BYTES in 16-bit cells: it takes k <= 32,639 (2 (k + 128) < 65,536); one more
+    entry and the launch goes to the first-generation kernel.  Same lists either side of the limit (N = 32,768 rows: the
+    largest shard), prepared and plain database."""
+    Q, N, nbits = 3, 32768, 64
+    q, r = synth.random_codes(Q, N, nbits, seed=91)
+    qp, rp = H.pack_codes(q.cuda()), H.pack_codes(r.cuda())
+    ref_idx, ref_d = ranking.hamming_topk_stable(q, r, k)
+    for db in (rp, H.PreparedDB(rp, nbits)):
+        idx, d = H.hamming_topk(qp, db, nbits, k)
+        assert torch.equal(idx.cpu().long(), ref_idx) and torch.equal(d.cpu().long(), ref_d)
