@@ -120,3 +120,13 @@ def test_wavelet_table_matches_oracle_table():
     with pytest.raises(ValueError):
         get_filters("nope")
     assert get_filters(([1, 2], [3, 4])) == ([1.0, 2.0], [3.0, 4.0])
+
+
+def test_plain_c_program_runs_the_host_twins_without_a_gpu():
+    """tests/native/host_smoke.c: gcc -std=c99 on include/wvhash.h (the header is C), linked against libwvhash.so, calling
+    only `_cpu` entry points -- closed-form SWT, packing, distances, stable ranking, AP, hit counts, argument validation --
+    on this GPU-less box: the host side of the boundary needs neither torch nor HIP headers nor a device."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "native"), "host_smoke"], stdout=subprocess.DEVNULL)
+    res = subprocess.run([os.path.join(ROOT, "tests", "native", "host_smoke")], capture_output=True, text=True, timeout=60)
+    assert res.returncode == 0 and "host_smoke ok" in res.stdout, res.stderr
