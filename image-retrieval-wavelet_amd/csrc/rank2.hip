@@ -324,36 +324,43 @@ __device__ __forceinline__ void rank2_ap(const uint16_t *stage, const uint32_t *
 {
     constexpr int NW = TPQ / 64;
     const int lane = t & 63, wv = t >> 6;
-    const int R = (k + TPQ - 1) / TPQ;                           // <= kApRounds (host check)
-    uint32_t *cnt = scratch;                                     // [R][NW] hits of a wave in a round
+    const int R = (k + TPQ - 1) / TPQ;                           // rounds; walked in chunks of kApRounds
+    uint32_t *cnt = scratch;                                     // [chunk rounds][NW] hits of a wave in a round
+    double *wsum = reinterpret_cast<double *>(scratch + kApRounds * NW + (kApRounds * NW & 1));
     // Eight rounds at a time, every LDS read of a batch issued before the first is used: with other workgroups' atomics
     // queued at the LDS unit a read takes ~1k cycles, and a chain of dependent ones (list entry -> bitmap word, round
     // after round) would pay that 2 R times.
-    uint32_t relbits = 0;
     constexpr int CH = 8;
-    for (int r0 = 0; r0 < R; r0 += CH) {
-        uint32_t it[CH], wd[CH];
+    ApState st;
+    for (int c0 = 0; c0 < R; c0 += kApRounds) {                  // one chunk for k <= 32 * TPQ (mAP@5000); more for mAP@ALL
+        const int Rc = min(kApRounds, R - c0);
+        uint32_t relbits = 0;
+        for (int r0 = c0; r0 < c0 + Rc; r0 += CH) {
+            uint32_t it[CH], wd[CH];
 #pragma unroll
-        for (int u = 0; u < CH; ++u) it[u] = stage[min((r0 + u) * TPQ + t, k - 1)];
+            for (int u = 0; u < CH; ++u) it[u] = stage[min((r0 + u) * TPQ + t, k - 1)];
 #pragma unroll
-        for (int u = 0; u < CH; ++u) wd[u] = bitmap[it[u] >> 5];
+            for (int u = 0; u < CH; ++u) wd[u] = bitmap[it[u] >> 5];
 #pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            const int r = r0 + u;
-            const bool rel = r < R && r * TPQ + t < k && ((wd[u] >> (it[u] & 31)) & 1u);
-            relbits |= (rel ? 1u : 0u) << (r & 31);
-            const uint64_t m = __ballot(rel);
-            if (lane == 0 && r < R) {
-                cnt[r * NW + wv] = (uint32_t)__popcll(m);
-                if (relbits_out && (r * NW + wv) * 64 < k) relbits_out[r * NW + wv] = m;
+            for (int u = 0; u < CH; ++u) {
+                const int r = r0 + u;
+                const bool rel = r < c0 + Rc && r * TPQ + t < k && ((wd[u] >> (it[u] & 31)) & 1u);
+                relbits |= (rel ? 1u : 0u) << ((r - c0) & 31);
+                const uint64_t m = __ballot(rel);
+                if (lane == 0 && r < c0 + Rc) {
+                    if (!relbits_out) cnt[(r - c0) * NW + wv] = (uint32_t)__popcll(m);
+                    else if ((r * NW + wv) * 64 < k) relbits_out[r * NW + wv] = m;
+                }
             }
         }
+        if (relbits_out) continue;                               // a shard of the sharded mAP: the string is all it sends
+        group_sync<TPQ>();                                       // the chunk's hit counts are published
+        ap_accum<TPQ>(relbits, cnt, Rc, c0, t, st);
+        group_sync<TPQ>();                                       // ... and read: the next chunk may overwrite them
     }
-    if (relbits_out) return;                                     // a shard of the sharded mAP: the string is all it sends
-    ap_finish<TPQ>(relbits, scratch, R, t, ap_out, nrel_out, [] { group_sync<TPQ>(); });
+    if (relbits_out) return;
+    ap_final<TPQ>(st, wsum, t, ap_out, nrel_out, [] { group_sync<TPQ>(); });
 }
-
-// LDS of one query group: [count table][staged list + trash slots][gbase, tot, misc][relevance bitmap (AP)]
 template <int TPQ>
 __device__ __forceinline__ Rank2Lds rank2_lds(uint8_t *lds_raw, int k)
 {
@@ -876,7 +883,7 @@ int rank2_launch(const uint64_t *q, const void *img, int32_t *idx, uint16_t *row
     const int nbins = nbits + 1, words = (nbits + 63) / 64;
     Rank2Ap apx{reinterpret_cast<const uint32_t *>(lab_img), qlab, lwords, ap, nrel, relbits, relbits_ld, cum_ld};
     if (ap || relbits) {
-        if (!lab_img || !qlab || k < 1 || k > kApRounds * tpq || lwords < 1 || lwords > 2) return 1;                     // the AP walk keeps <= 32 positions per thread
+        if (!lab_img || !qlab || k < 1 || lwords < 1 || lwords > 2) return 1;
         const size_t per_g = tpq == 64 ? 4 * rank2_lds_bytes_per_query<64>(k, rank2_bitmap_words(N))
                                        : rank2_lds_bytes_per_query<256>(k, rank2_bitmap_words(N));
         if (per_g > 100 * 1024) return 1;

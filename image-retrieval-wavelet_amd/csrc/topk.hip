@@ -937,15 +937,23 @@ __global__ __launch_bounds__(256) void k_merge_relbits_ap(const uint32_t *__rest
     }
     __syncthreads();
     const int R = (k + 255) / 256;
-    uint32_t mine = 0;
-    for (int r = 0; r < R; ++r) {
-        const int p = r * 256 + tid;
-        const bool rel = p < k && ((M[p >> 5] >> (p & 31)) & 1u);
-        mine |= (rel ? 1u : 0u) << r;
-        const uint64_t m = __ballot(rel);
-        if (lane == 0) scratch[r * 4 + wv] = (uint32_t)__popcll(m);
+    double *wsum = reinterpret_cast<double *>(scratch + kApRounds * 4 + (kApRounds * 4 & 1));
+    ApState st;
+    for (int c0 = 0; c0 < R; c0 += kApRounds) {                   // chunks of 32 rounds: any k (mAP@ALL: k = database size)
+        const int Rc = min(kApRounds, R - c0);
+        uint32_t mine = 0;
+        for (int r = 0; r < Rc; ++r) {
+            const int p = (c0 + r) * 256 + tid;
+            const bool rel = p < k && ((M[p >> 5] >> (p & 31)) & 1u);
+            mine |= (rel ? 1u : 0u) << r;
+            const uint64_t m = __ballot(rel);
+            if (lane == 0) scratch[r * 4 + wv] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        ap_accum<256>(mine, scratch, Rc, c0, tid, st);
+        __syncthreads();
     }
-    ap_finish<256>(mine, scratch, R, tid, ap + qi, nrel ? nrel + qi : nullptr, [] { __syncthreads(); });
+    ap_final<256>(st, wsum, tid, ap + qi, nrel ? nrel + qi : nullptr, [] { __syncthreads(); });
 }
 }  // namespace wv
 
@@ -1183,7 +1191,6 @@ extern "C" int wv_merge_relbits_map(const uint64_t *relbits, int64_t relbits_ld,
     WV_REQUIRE(relbits && cum && ap, "merge_relbits_map: null buffer");
     WV_REQUIRE(G >= 1 && Q >= 0 && kin >= 1 && k >= 1, "merge_relbits_map: bad shape G=%d Q=%d kin=%d k=%d", G, Q, kin, k);
     WV_REQUIRE(nbits >= 1 && nbits <= 128, "merge_relbits_map: nbits=%d (supported: 1..128)", nbits);
-    if (k > kApRounds * 256) WV_FAIL(WV_ENOTSUP, "merge_relbits_map: k=%d > %d", k, kApRounds * 256);
     if (Q == 0) return WV_OK;
     const int nbins = nbits + 1, w32 = 2 * (int)ceil_div(kin, 64), mwords = (k + 31) / 32 + 1;
     const size_t lds = ((size_t)G * (nbins + 1) + nbins + 1 + mwords + (mwords & 1) + ap_scratch_dwords<256>() + 4) * 4;

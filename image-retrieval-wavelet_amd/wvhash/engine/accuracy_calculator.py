@@ -232,7 +232,7 @@ class CustomCalculator(object):
             raise ZeroDivisionError("calculate_maphashing: no queries")
         ap = None
         nbits = reference.shape[1]
-        if self.rank_cache is None and not self.host and nbits <= 128 and topk <= 8192:
+        if self.rank_cache is None and not self.host and nbits <= 128:
             # one k, nothing to share: ranking and AP in one kernel, the lists never leave the GPU's LDS
             # (same numbers as the two steps below; None = shape outside the fused kernel)
             qlp, rlp = self._packed_labels(query_labels, reference_labels)

@@ -255,7 +255,7 @@ def evaluate_sharded(net, test_dataset, k=5000, epoch=None, batch_size=64, num_w
       prefixes, all_to_all, GPU merge -- the role faiss.index_cpu_to_all_gpus(shards=True) plays in the reference
       (main/engine/get_knn.py:41-44), whose embedding sweep runs under nn.DataParallel (evaluate.py:70-71);
     * mAP comes from relevance strings (wvhash.parallel.sharded_hamming_map_at_k: a shard ranks against its own rows' labels,
-      1 bit per list entry on the wire) whenever the shape allows -- up to 128 classes, 128 bits, k <= 8192, shards of at
+      1 bit per list entry on the wire) whenever the shape allows -- up to 128 classes, 128 bits, any k (mAP@ALL included), shards of at
       most 32,768 rows: MIRFLICKR and COCO at k = 5000; otherwise lists are exchanged, the packed database labels
       all-gathered (8 bytes per row and label word) and AP computed from the merged lists: the same numbers;
     * the AP sums and the per-bit counts are all-reduced.
@@ -311,7 +311,7 @@ def evaluate_sharded(net, test_dataset, k=5000, epoch=None, batch_size=64, num_w
         rlp_local[:hi - lo] = H.pack_labels(r_lab.float())
     k_eff = min(int(k), n_db) if k is not None else n_db
     ap = None
-    if world > 1 and lw in (1, 2) and nbits <= 128 and k_eff <= 8192 and per_db <= H.SHARD_ROWS_MAX:
+    if world > 1 and lw in (1, 2) and nbits <= 128 and min(k_eff, per_db) <= H.RANK_K_MAX and per_db <= H.SHARD_ROWS_MAX:
         # mAP from relevance strings: no list and no database label leaves its GPU (decided from values every rank shares)
         shard_labels = H.PreparedLabels(rlp_local[:hi - lo].contiguous()) if hi > lo else None
         got = sharded_hamming_map_at_k(qp, qlp, H.PreparedDB(rp, nbits), shard_labels, nbits, k_eff, n_db, None, group=group)

@@ -66,6 +66,7 @@ def bit_counts(packed, nbits):
 
 
 SHARD_ROWS_MAX = 32768      # wv_hamming_hist / wv_hamming_topk_rows16 take shards up to this many rows
+RANK_K_MAX = 32639          # longest list the windowed kernel builds (its 16-bit cells count list bytes: 2 (k + 128) < 65536)
 
 
 class PreparedDB:
@@ -392,10 +393,12 @@ def hamming_map_at_k(q_packed, db, labels, qlab_packed, nbits, k):
     if not labels.ok or qlab_packed.shape[1] != labels.words or nbits > 128 or not 1 <= k <= db.N:
         return None
     if db.parts or labels.parts:                         # more than 32,768 rows: virtual shards, relevance strings, one merge
-        if not (db.parts and labels.parts) or len(db.parts) != len(labels.parts) or k > 8192 or not Q:
+        if not (db.parts and labels.parts) or len(db.parts) != len(labels.parts) or not Q:
             return None
         cums = torch.stack([hamming_hist(q_packed, part, nbits) for part in db.parts])
         send = max(1, min(k, db.per, _prefix_need(cums, k)))
+        if send > RANK_K_MAX:
+            return None
         wires = torch.zeros((len(db.parts), Q, relbits_wire_words(send, nbits)), dtype=torch.int64, device=q_packed.device)
         for g, (part, lab) in enumerate(zip(db.parts, labels.parts)):
             if hamming_shard_relbits(q_packed, part, lab, qlab_packed, nbits, min(send, part.N), wire=wires[g], kin=send) is None:

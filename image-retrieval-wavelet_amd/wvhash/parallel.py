@@ -265,7 +265,7 @@ def sharded_hamming_map_at_k(q_local, qlab_local, db_shard, labels_shard, nbits,
     lo, hi, per = shard_bounds(n_total, world, rank)
     n_local = hi - lo
     lwords = qlab_local.shape[1]                         # 1 label word (<= 64 classes) or 2 (COCO's 80, NUS-WIDE's 81)
-    if per > H.SHARD_ROWS_MAX or k > 8192 or lwords not in (1, 2) or nbits > 128:
+    if per > H.SHARD_ROWS_MAX or min(k, per) > H.RANK_K_MAX or lwords not in (1, 2) or nbits > 128:
         return None                                      # decided from values every rank shares: no rank goes another way
     dev = q_local.device
     both = torch.cat([q_local, qlab_local], dim=1).contiguous()           # codes | label words: one collective

@@ -211,7 +211,8 @@ int wv_hamming_topk_ex(const uint64_t *q, const uint64_t *db, const void *prepar
  *   prepared         wv_db_prepare's blob of the database codes
  *   prepared_labels  wv_rank_labels_prepare's class-major bit matrix of the rows' label words
  *                    (wv_rank_labels_prepared_bytes(N) bytes; 0 = N is outside the windowed kernel)
- * Returns WV_ENOTSUP for shapes outside the fused kernel (more than 32,768 rows, k > 8,192, ...): the caller then runs
+ * Returns WV_ENOTSUP for shapes outside the fused kernel (more than 32,768 rows, k > 32,639 -- the list is built in LDS with
+ * 16-bit cells --, lists that do not fit LDS beside the label bitmap, ...; mAP@ALL with k = N is inside for N <= 32,639): the caller then runs
  * wv_hamming_topk + wv_map_at_k. */
 size_t wv_rank_labels_prepared_bytes(int64_t N, int lwords);
 int wv_rank_labels_prepare(const uint64_t *dblab, int64_t N, int lwords, void *prepared_labels, size_t prepared_bytes, void *stream);
@@ -271,7 +272,8 @@ int wv_topk_merge_cum_need(const uint16_t *idx_local, const uint32_t *cum, int G
  *                             need_out as in wv_topk_merge_cum_need
  * relbits_ld / cum_ld: row pitches in uint64 / uint32 units (0 = tight): string and histogram of a (query, shard) may lie side
  * by side in ONE wire buffer, so that a single all_to_all moves both.
- * WV_ENOTSUP outside the windowed kernel's range (shards of more than 32,768 rows, k > 8,192, wider labels). */
+ * WV_ENOTSUP outside the windowed kernel's range (shards of more than 32,768 rows, k > 32,639, wider labels); any k inside it:
+ * a shard can send the relevance string of its whole ranking (mAP@ALL). */
 int wv_hamming_shard_relbits(const uint64_t *q, const void *prepared, const void *prepared_labels, const uint64_t *qlab,
                              int lwords, uint64_t *relbits, int64_t relbits_ld, uint32_t *cum, int64_t cum_ld, int Q, int64_t N,
                              int nbits, int k, void *stream);
