@@ -64,8 +64,10 @@ def parse():
     ap.add_argument("--queries", type=int, default=Q_PER_GPU, help="query images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grid", action="store_true", help="skip the kernel rows that are not part of the step (c0 / c3 / SURVEY 8(d) grid)")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("WV_BENCH_STREAMS", "1")), choices=(1, 2),
-                    help="2: the SWT of a batch runs on its own HIP stream beside head/hash/ranking (stage pipelining)")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("WV_BENCH_STREAMS", "0")), choices=(0, 1, 2),
+                    help="2: the SWT of a batch runs on its own HIP stream, started when the head is done, beside hash tail, search "
+                         "and collectives (stage pipelining); 1: everything on one stream; 0 (default): 1 on one GPU -- where the two "
+                         "are equal within noise -- and 2 on several, where the exchange's latency hides behind the transform")
     ap.add_argument("--kernel-reps", type=int, default=10, help="launches per stage for the roofline timing")
     return ap.parse_args()
 
@@ -183,9 +185,17 @@ class Pipeline:
     def step(self):
         if self.swt_stream is not None:
             # stage pipelining: in the full system the backbone sits between the SWT and the head, so in steady
-            # state the transform of one batch runs beside head/hash/ranking of the previous one
+            # state the transform of one batch runs beside head/hash/ranking of the previous one.  The head goes FIRST: its
+            # one-launch front takes 149 KB of LDS per CU and cannot share a CU with the transform's workgroups (2 x 58 KB) --
+            # submitted after the persistent transform it would wait for all of it; submitted before, the transform starts
+            # as the front's workgroups retire and everything behind the front (read-out, hash tail, search, collectives)
+            # runs beside it.
             main = torch.cuda.current_stream()
-            self.swt_stream.wait_stream(main)
+            if self.marks_all:
+                self._mark("step0")
+            fused = self.stage_head()
+            self._mark("head1")
+            self.swt_stream.wait_stream(main)            # the transform starts when the head (and the previous step) is done
             with torch.cuda.stream(self.swt_stream):
                 self._mark("swt0", self.swt_stream)
                 bands = self.stage_swt()
@@ -194,8 +204,8 @@ class Pipeline:
             self._mark("swt0")
             bands = self.stage_swt()
             self._mark("swt1")
-        fused = self.stage_head()
-        self._mark("head1")
+            fused = self.stage_head()
+            self._mark("head1")
         packed = self.stage_tail(fused)
         self._mark("tail1")
         fused_ap = (self.Hm.hamming_map_at_k(packed, self.db_shard, self.lab_prepared, self.qlab, NBITS, TOPK)
@@ -249,6 +259,14 @@ def stage_times_in_pipeline(p, reps):
     acc = {}
     for r in range(reps):
         m = marks[r * per:(r + 1) * per]
+        if p.swt_stream is not None:
+            # two streams: the stages overlap; report each stage from the event before it ON ITS OWN stream
+            ev = dict(m)
+            pairs = [("swt1", "swt0"), ("head1", "step0"), ("tail1", "head1"), ("rankmap1", "tail1"), ("rank1", "tail1"), ("map1", "rank1")]
+            for name, prev in pairs:
+                if name in ev and prev in ev:
+                    acc[name] = acc.get(name, 0.0) + ev[prev].elapsed_time(ev[name])
+            continue
         for (_, e0), (name, e1) in zip(m[:-1], m[1:]):
             acc[name] = acc.get(name, 0.0) + e0.elapsed_time(e1)
     return {k: v / reps for k, v in acc.items()}
@@ -625,15 +643,25 @@ def per_rank_breakdown(p, reps=5):
     marks, p.marks, p.marks_all = p.marks, None, False
     trace, parallel.TRACE = parallel.TRACE, None
     per = len(marks) // reps
-    step_ms = sum(marks[r * per][1].elapsed_time(marks[(r + 1) * per - 1][1]) for r in range(reps)) / reps
     coll = {k: v / reps for k, v in trace.ms().items()}
-    stages = {}
+    stages, step_ms = {}, 0.0
     for r in range(reps):
         m = marks[r * per:(r + 1) * per]
+        if p.swt_stream is not None:                         # two streams: a stage is measured from the event before it on ITS stream
+            ev = dict(m)
+            for name, prev in (("swt1", "swt0"), ("head1", "step0"), ("tail1", "head1"), ("rankmap1", "tail1"), ("rank1", "tail1"),
+                               ("map1", "rank1")):
+                if name in ev and prev in ev:
+                    stages[name] = stages.get(name, 0.0) + ev[prev].elapsed_time(ev[name]) / reps
+            step_ms += max(ev["step0"].elapsed_time(ev["swt1"]), ev["step0"].elapsed_time(m[-1][1])) / reps
+            continue
+        step_ms += m[0][1].elapsed_time(m[-1][1]) / reps
         for (_, e0), (name, e1) in zip(m[:-1], m[1:]):
             stages[name] = stages.get(name, 0.0) + e0.elapsed_time(e1) / reps
     return {"rank": p.rank, "step_ms": round(step_ms, 4), "collectives_ms": {k: round(v, 4) for k, v in coll.items() if v},
-            "kernels_ms": round(step_ms - sum(coll.values()), 4),
+            "kernels_ms": round(step_ms - (sum(coll.values()) if p.swt_stream is None else 0.0), 4),
+            "note": ("two streams: the transform runs beside hash tail, search and collectives, so the stages overlap and step_ms "
+                     "is the longer of the two streams") if p.swt_stream is not None else "one stream: step_ms = kernels_ms + collectives_ms",
             "stage_ms": {"swt": round(stages.get("swt1", 0.0), 4), "head": round(stages.get("head1", 0.0), 4),
                          "hash_tail": round(stages.get("tail1", 0.0), 4),
                          "search (kernels + collectives)": round(stages.get("rankmap1", stages.get("rank1", 0.0) + stages.get("map1", 0.0)), 4)},
@@ -658,8 +686,9 @@ def run(args, rank, world, device):
 
     # ---- setup; a rank that fails here tells the others instead of leaving them in their first collective
     p, setup_error = None, None
+    streams = args.streams or (2 if world > 1 else 1)
     try:
-        p = Pipeline(args.queries, rank, world, device, streams=args.streams)
+        p = Pipeline(args.queries, rank, world, device, streams=streams)
     except Exception as e:                                   # noqa: BLE001
         setup_error = e
         print(f"[bench rank {rank}] setup failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
@@ -748,7 +777,7 @@ def run(args, rank, world, device):
             "queries_per_gpu": args.queries, "db_codes": N_DB, "nbits": NBITS, "k": TOPK,
             "wavelet": WAVELET, "level": LEVEL,
             "arithmetic": "fp32 SWT and head (fp32 MFMA), 64-bit popcount ranking, AP in fp32/fp64",
-            "streams": args.streams,
+            "streams": streams,
             "clock_steps": args.clock_steps,   # untimed steps before the warm-up steps (GPU clock ramp after idle)
             "swt_output_placement": p.placement,  # setup: fastest of several candidate allocations of the sub-band buffer
             "host_syncs_in_timed_steps": host_syncs,
