@@ -138,16 +138,13 @@ __device__ __forceinline__ float key_to_float(uint32_t u, bool descending)
 // to idx_out / val_out.
 // Intermediate (key, idx) arrays are kept in the column image pos -> [pos % C][pos / C] ("transposed"), so
 // that thread t's contiguous range [t*C, (t+1)*C) of the NEXT pass is read with coalesced loads.
-__global__ __launch_bounds__(kRadixThreads) void k_radix_pass(const float *__restrict__ S,
-                                                              const uint2 *__restrict__ src,
-                                                              uint2 *__restrict__ dst, int64_t N, int C,
-                                                              uint32_t c_magic, int shift, int first, int last,
-                                                              int k, int descending, int32_t *__restrict__ idx_out,
-                                                              float *__restrict__ val_out)
+// (a device function: k_row_radix below runs the selection and all six passes of a row in ONE launch -- a row never
+// leaves its workgroup, so the passes need a barrier between them, not a kernel boundary)
+__device__ __forceinline__ void radix_pass(uint32_t *hist, uint32_t *tot, uint32_t *base, const float *__restrict__ S,
+                                           const uint2 *src, uint2 *dst, int64_t N, int C, uint32_t c_magic, int shift,
+                                           int first, int last, int k, int descending, int32_t *__restrict__ idx_out,
+                                           float *__restrict__ val_out)
 {
-    __shared__ uint32_t hist[kRadixBins * kRadixThreads];  // 64 KB
-    __shared__ uint32_t tot[kRadixBins];
-    __shared__ uint32_t base[kRadixBins];
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     const int64_t row = blockIdx.x;
     const int64_t pitch = (int64_t)C * kRadixThreads;   // padded row length of the transposed images
@@ -238,6 +235,7 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_pass(const float *__res
         place(kv, __hip_atomic_fetch_add(&hist[((kv.x >> shift) & (kRadixBins - 1)) * kRadixThreads + tid], 1u,
                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     }
+    __syncthreads();   // the next pass zeroes the columns and reads what this one stored (same workgroup, same CU)
 }
 
 // Selection before sorting (k <= N/2): the full LSD sort moves every one of the N (key, index) pairs six times,
@@ -247,12 +245,10 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_pass(const float *__res
 // that fill up to exactly k, straight into the column image the radix passes read.  The six passes then sort k
 // items instead of N.  Same result as the full sort: ascending (key, index).
 constexpr int kSelBins = 2048;
-__global__ __launch_bounds__(256) void k_select_compact(const float *__restrict__ S, uint2 *__restrict__ dst, int64_t N,
-                                                        int k, int Ck, uint32_t ck_magic, int descending)
+__device__ __forceinline__ void select_compact(uint32_t *hist, uint32_t *wpart, uint32_t *sel,
+                                               const float *__restrict__ S, uint2 *dst, int64_t N, int k, int Ck,
+                                               uint32_t ck_magic, int descending)
 {
-    __shared__ uint32_t hist[kSelBins];
-    __shared__ uint32_t wpart[8];
-    __shared__ uint32_t sel[2];          // chosen bin, items before it
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     const int64_t row = blockIdx.x;
     const float *Srow = S + row * N;
@@ -323,6 +319,265 @@ __global__ __launch_bounds__(256) void k_select_compact(const float *__restrict_
     }
 }
 
+// The radix ranking of one row, one launch: [selection of the k best] + six stable counting-sort passes.
+// todo != null: only rows k_row_topk (below) handed over; every other workgroup returns at once.
+__global__ __launch_bounds__(kRadixThreads) void k_row_radix(const float *__restrict__ S, uint2 *bufA, uint2 *bufB,
+                                                             int64_t N, int C, uint32_t c_magic, int k, int Ck,
+                                                             uint32_t ck_magic, int select_first, int descending,
+                                                             int32_t *__restrict__ idx_out, float *__restrict__ val_out,
+                                                             const uint8_t *__restrict__ todo)
+{
+    if (todo && !todo[blockIdx.x]) return;
+    __shared__ uint32_t hist[kRadixBins * kRadixThreads];  // 64 KB (the selection's 2048 bins live in its head)
+    __shared__ uint32_t tot[kRadixBins];
+    __shared__ uint32_t base[kRadixBins];
+    constexpr int npass = 32 / kRadixBits + (32 % kRadixBits != 0);
+    if (select_first) {
+        // radix-select the k best of the row, then sort only those (the images keep the N-sized pitch)
+        select_compact(hist, tot, base, S, bufB, N, k, Ck, ck_magic, descending);
+        __syncthreads();
+        for (int p = 0; p < npass; ++p)
+            radix_pass(hist, tot, base, S, (p & 1) ? bufA : bufB, (p & 1) ? bufB : bufA, (int64_t)k, Ck, ck_magic,
+                       p * kRadixBits, 0, p == npass - 1, k, descending, idx_out, val_out);
+        return;
+    }
+    for (int p = 0; p < npass; ++p)
+        radix_pass(hist, tot, base, S, (p & 1) ? bufA : bufB, (p & 1) ? bufB : bufA, N, C, c_magic, p * kRadixBits,
+                   p == 0, p == npass - 1, k, descending, idx_out, val_out);
+}
+
+// ---- one kernel per row for k <= 15,360: the list is selected, sorted and written without leaving the CU ----------
+// k_select_compact + six k_radix_pass launches move every survivor through global memory seven times with scattered
+// 8-byte stores (0.87 ms of the 1.16 ms of a 2048 x 25,000, k = 5000 search), and the selection's 11-bit histograms
+// of raw key bits pile a whole row onto the few bins of its sign / exponent.  Here the digit is a VALUE bin instead:
+//   bin(w) = clamp(floor(64 + (w - lo) * 3968 / (hi - lo)), 0, 4095),   w = the score in ascending rank order
+//   (v for L2, -v for IP), [lo, hi] = min / max of a strided 4096-item sample of the row.
+// Every step of bin() is monotone non-decreasing under IEEE rounding, so bin(x) < bin(y) implies x < y and equal
+// keys share a bin -- for ANY lo / hi (a poor range costs time, never correctness).  One histogram pass finds the
+// bin b* that holds the k-th item; a second pass drops every item of bins <= b* into its bin's slot range of an LDS
+// list (order inside a bin arbitrary); each item then counts the items of its own bin that precede it as
+// (key, index) pairs -- a handful for smooth scores -- which is its final rank; the list is permuted in place and
+// its first k entries leave as two coalesced streams.  Rows this cannot take (a bin holding more than 512
+// survivors, NaNs, a boundary bin that overflows the list: ties en masse, constant rows) set todo[row] and the radix
+// kernels above rank exactly those rows; they return at once for all others.
+constexpr int kTkThreads = 1024;
+constexpr int kTkBins = 4096;
+constexpr int kTkSlack = 1024;        // list entries beyond k for the rest of the boundary bin
+constexpr int kTkCapMax = 16384;      // 16 entries per thread are held in registers across the in-place permutation
+constexpr int kTkGroupMax = 512;
+constexpr int kTkSample = 4096;
+#ifndef WV_TK_UNROLL
+#define WV_TK_UNROLL 8
+#endif
+constexpr int kTkUnroll = WV_TK_UNROLL;
+
+__device__ __forceinline__ float tk_order_value(float v, bool descending)
+{
+    v += 0.0f;   // -0 -> +0, as float_to_key
+    return descending ? -v : v;
+}
+__device__ __forceinline__ int tk_bin(float w, float lo, float scale)
+{
+    return (int)fminf(fmaxf(fmaf(w - lo, scale, 64.f), 0.f), (float)(kTkBins - 1));
+}
+
+static size_t tk_lds_bytes(int cap) { return (size_t)(kTkBins + 32 + 32 + 8) * 4 + (size_t)cap * 8; }
+
+// exclusive prefix over the bins (thread t owns bins 4t .. 4t+3): returns the prefix of bin 4t, the four counts in c
+__device__ __forceinline__ uint32_t tk_scan_bins(const uint32_t *cnt, uint32_t *wpart, uint4 &c)
+{
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    c = *reinterpret_cast<const uint4 *>(cnt + 4 * tid);
+    const uint32_t sum = c.x + c.y + c.z + c.w;
+    const uint32_t incl = wave_incl_scan_u32(sum);
+    if (lane == 63) wpart[wv] = incl;
+    __syncthreads();
+    uint32_t e0 = incl - sum;
+    for (int w2 = 0; w2 < wv; ++w2) e0 += wpart[w2];
+    return e0;
+}
+
+template <int JMAX>
+__global__ __launch_bounds__(kTkThreads) void k_row_topk(const float *__restrict__ S, int64_t N, int k, int cap,
+                                                         int descending, int32_t *__restrict__ idx_out,
+                                                         float *__restrict__ val_out, uint8_t *__restrict__ todo,
+                                                         int force_radix)
+{
+    extern __shared__ uint4 tk_sm4[];
+    uint32_t *cursor = reinterpret_cast<uint32_t *>(tk_sm4);   // [4096] counts -> exclusive prefix -> running cursor
+    uint32_t *wpart = cursor + kTkBins;                         // [32]   wave totals of the scan
+    float *fpart = reinterpret_cast<float *>(wpart + 32);       // [32]   wave minima, wave maxima
+    uint32_t *sel = reinterpret_cast<uint32_t *>(fpart + 32);   // [8]    see the enum
+    uint64_t *A = reinterpret_cast<uint64_t *>(sel + 8);        // [cap]  (key << 32 | index)
+    enum { BSTAR = 0, BEFORE = 1, COUNT = 2, NAN_SEEN = 3, GMAX = 4 };
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int64_t row = blockIdx.x;
+    const float *Srow = S + row * N;
+    const bool desc = descending != 0;
+#ifdef WV_TK_STOPS   // phase timing by truncation (tools/knn_phases.py): the kernel ends after phase force_radix >> 8
+    const int stop_at = force_radix >> 8;
+    force_radix &= 0xff;
+#define TK_STOP(n) if (stop_at == (n)) return
+#else
+#define TK_STOP(n)
+#endif
+
+    // range of the row from a sample: 64 runs of 64 consecutive scores spread over the row (the whole row if short)
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    {
+        const bool sampled = N > kTkSample;
+        const int64_t stride = N / 64;
+#pragma unroll
+        for (int j = 0; j < kTkSample / kTkThreads; ++j) {
+            const int s = tid + kTkThreads * j;
+            const int64_t i = sampled ? (int64_t)(s >> 6) * stride + (s & 63) : (int64_t)s;
+            if (i < N) {
+                const float w = tk_order_value(Srow[i], desc);
+                mn = fminf(mn, w);
+                mx = fmaxf(mx, w);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, d, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    }
+    if (lane == 0) { fpart[wv] = mn; fpart[16 + wv] = mx; }
+    *reinterpret_cast<uint4 *>(cursor + 4 * tid) = make_uint4(0, 0, 0, 0);
+    if (tid < 8) sel[tid] = 0;
+    __syncthreads();
+    float lo = fpart[0], hi = fpart[16];
+#pragma unroll
+    for (int w2 = 1; w2 < kTkThreads / 64; ++w2) {
+        lo = fminf(lo, fpart[w2]);
+        hi = fmaxf(hi, fpart[16 + w2]);
+    }
+    float scale = (float)(kTkBins - 128) / (hi - lo);
+    if (!(scale > 0.f)) scale = 0.f;                 // constant sample, infinite range, NaN: everything in one bin
+    TK_STOP(1);
+
+    // pass 1: value-bin histogram of the whole row
+    constexpr int UNR = kTkUnroll;
+    bool nan_seen = false;
+    for (int64_t i0 = tid; i0 < N; i0 += (int64_t)kTkThreads * UNR) {
+        float v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t i = i0 + (int64_t)u * kTkThreads;
+            v[u] = Srow[min(i, N - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (i0 + (int64_t)u * kTkThreads >= N) break;
+            const float w = tk_order_value(v[u], desc);
+            nan_seen |= w != w;
+            __hip_atomic_fetch_add(&cursor[tk_bin(w, lo, scale)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    if (nan_seen) sel[NAN_SEEN] = 1;
+    __syncthreads();
+    TK_STOP(2);
+
+    // exclusive prefix over the bins; the bin where the running count reaches k
+    {
+        uint4 c;
+        const uint32_t e0 = tk_scan_bins(cursor, wpart, c), e1 = e0 + c.x, e2 = e1 + c.y, e3 = e2 + c.z;
+        *reinterpret_cast<uint4 *>(cursor + 4 * tid) = make_uint4(e0, e1, e2, e3);
+        const uint32_t kk = (uint32_t)k;
+        const uint32_t e[4] = {e0, e1, e2, e3}, cc[4] = {c.x, c.y, c.z, c.w};
+        uint32_t g = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (e[b] < kk && kk <= e[b] + cc[b]) { sel[BSTAR] = 4 * tid + b; sel[BEFORE] = e[b]; sel[COUNT] = cc[b]; }
+            g = max(g, e[b] < kk ? cc[b] : 0u);
+        }
+        const uint32_t gw = (uint32_t)__reduce_max_sync(~0ull, g);
+        if (lane == 0) __hip_atomic_fetch_max(&sel[GMAX], gw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    const int bstar = (int)sel[BSTAR];
+    const uint32_t n_tot = sel[BEFORE] + sel[COUNT];
+    if (n_tot > (uint32_t)cap || sel[GMAX] > (uint32_t)kTkGroupMax || sel[NAN_SEEN] || force_radix) {
+        if (tid == 0) todo[row] = 1;
+        return;
+    }
+    if (tid == 0) todo[row] = 0;
+    TK_STOP(3);
+
+    // pass 2: every item of a bin <= b* takes the next slot of its bin; afterwards cursor[b] is the END of bin b, i.e. the
+    // start of bin b + 1
+    for (int64_t i0 = tid; i0 < N; i0 += (int64_t)kTkThreads * UNR) {
+        float v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t i = i0 + (int64_t)u * kTkThreads;
+            v[u] = Srow[min(i, N - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t i = i0 + (int64_t)u * kTkThreads;
+            if (i >= N) break;
+            const int b = tk_bin(tk_order_value(v[u], desc), lo, scale);
+            if (b <= bstar)
+                A[__hip_atomic_fetch_add(&cursor[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] =
+                    ((uint64_t)float_to_key(v[u], desc) << 32) | (uint32_t)i;
+        }
+    }
+    __syncthreads();
+    TK_STOP(4);
+
+    // rank inside the bin = number of (key, index) pairs of the same bin that come first (four per trip: the reads of a
+    // trip are independent, a lane's neighbours are in the same bin and read the same addresses)
+    uint64_t item[JMAX];
+    uint32_t pos[JMAX];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)(kTkThreads * j);
+        pos[j] = 0xffffffffu;
+        if (i < n_tot) {
+            const uint64_t e = A[i];
+            const int b = tk_bin(tk_order_value(key_to_float((uint32_t)(e >> 32), desc), desc), lo, scale);
+            const uint32_t s = b ? cursor[b - 1] : 0u, end = cursor[b];
+            uint32_t before = s;
+            for (uint32_t p = s; p < end; p += 4) {
+                const uint32_t last = end - 1;
+                const uint64_t a0 = A[p], a1 = A[min(p + 1, last)], a2 = A[min(p + 2, last)], a3 = A[min(p + 3, last)];
+                before += (a0 < e) + (p + 1 < end && a1 < e) + (p + 2 < end && a2 < e) + (p + 3 < end && a3 < e);
+            }
+            item[j] = e;
+            pos[j] = before;
+        }
+    }
+    __syncthreads();
+    TK_STOP(5);
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j)
+        if (pos[j] != 0xffffffffu) A[pos[j]] = item[j];
+    __syncthreads();
+    for (int i = tid; i < k; i += kTkThreads) {
+        const uint64_t e = A[i];
+        idx_out[row * k + i] = (int32_t)(uint32_t)e;
+        val_out[row * k + i] = key_to_float((uint32_t)(e >> 32), desc);
+    }
+}
+
+template <int JMAX>
+static int launch_row_topk(const float *S, int64_t N, int k, int cap, int descending, int32_t *idx, float *val,
+                           uint8_t *todo, int force_radix, int rows, hipStream_t st)
+{
+    const size_t lds = tk_lds_bytes(cap);
+    auto kern = k_row_topk<JMAX>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) WV_FAIL(WV_EHIP, "knn_float: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3(kTkThreads), lds, st, S, N, k, cap, descending, idx, val, todo,
+                       force_radix);
+    return WV_OK;
+}
+
 static int64_t knn_chunk_rows(int Q, int64_t N)
 {
     // bound the scratch to about 2 GiB: per row N * (4 + 8 + 8) bytes
@@ -342,7 +597,7 @@ extern "C" size_t wv_knn_float_workspace_bytes(int Q, int64_t N, int D, int k)
     if (Q <= 0 || N <= 0) return 0;
     const int64_t rows = knn_chunk_rows(Q, N);
     const int64_t pitch = ceil_div(N, kRadixThreads) * kRadixThreads;
-    return (size_t)(rows * (N * 4 + pitch * 16) + (align_up(Q, 64) + align_up(N, 64)) * 4 + 1024);
+    return (size_t)(rows * (N * 4 + pitch * 16) + (align_up(Q, 64) + align_up(N, 64)) * 4 + align_up(rows, 256) + 1024);
 }
 
 extern "C" int wv_knn_float(const float *q, const float *db, int Q, int64_t N, int D, int metric, int k,
@@ -368,7 +623,8 @@ extern "C" int wv_knn_float(const float *q, const float *db, int Q, int64_t N, i
     uint2 *bufA = (uint2 *)w;              w += rows * pitch * 8;
     uint2 *bufB = (uint2 *)w;              w += rows * pitch * 8;
     float *qn = (float *)w;                w += align_up(Q, 64) * 4;
-    float *dbn = (float *)w;
+    float *dbn = (float *)w;               w += align_up(N, 64) * 4;
+    uint8_t *todo_buf = (uint8_t *)w;      // [rows] 1 = k_row_topk left the row to the radix kernels
     if (metric == WV_METRIC_L2) {
         hipLaunchKernelGGL(k_row_sqnorm, dim3((unsigned)ceil_div(Q, 4)), dim3(256), 0, st, q, (int64_t)Q, D, qn);
         hipLaunchKernelGGL(k_row_sqnorm, dim3((unsigned)ceil_div(N, 4)), dim3(256), 0, st, db, N, D, dbn);
@@ -380,30 +636,26 @@ extern "C" int wv_knn_float(const float *q, const float *db, int Q, int64_t N, i
         const int qc = (int)std::min<int64_t>(rows, Q - q0);
         dim3 grid((unsigned)ceil_div(N, 128), (unsigned)ceil_div(qc, 128));
         hipLaunchKernelGGL(k_scores, grid, dim3(256), 0, st, q + q0 * D, db, qn + q0, dbn, S, qc, N, D, metric);
-        const int npass = 6;
-        const uint2 *src = bufA;
-        uint2 *dst = bufA;
-        const bool select_first = (int64_t)k * 2 <= N && !::wv::tune("WV_KNN_FULLSORT");
-        if (select_first) {
-            // radix-select the k best of every row, then sort only those (the images keep the N-sized pitch)
-            const int Ck = (int)ceil_div(k, kRadixThreads);
-            const uint32_t ck_magic = Ck <= 1 ? 0u : (uint32_t)(((1ull << 32) + Ck - 1) / Ck);
-            hipLaunchKernelGGL(k_select_compact, dim3(qc), dim3(256), 0, st, S, bufB, N, k, Ck, ck_magic, descending);
-            for (int p = 0; p < npass; ++p) {
-                src = (p & 1) ? bufA : bufB;
-                dst = (p & 1) ? bufB : bufA;
-                hipLaunchKernelGGL(k_radix_pass, dim3(qc), dim3(kRadixThreads), 0, st, S, src, dst, (int64_t)k, Ck, ck_magic,
-                                   p * kRadixBits, 0, p == npass - 1, k, descending, idx + q0 * k, val + q0 * k);
-            }
-            continue;
+        // rows the one-kernel ranking takes never reach the radix kernels (they return at once on todo[row] == 0)
+        const uint8_t *todo = nullptr;
+        if (k + kTkSlack <= kTkCapMax && !::wv::tune("WV_KNN_RADIX_ONLY")) {
+            const int cap = (int)std::min<int64_t>(kTkCapMax, align_up(k + kTkSlack, kTkThreads));
+            int force = ::wv::tune("WV_KNN_FORCE_TODO") ? 1 : 0;   // diagnostic build: every row takes both kernels' hand-over
+            if (const char *stop = ::wv::tune("WV_TK_STOP")) force |= atoi(stop) << 8;
+            const int J = cap / kTkThreads;
+            int rc;
+            if (J <= 2) rc = launch_row_topk<2>(S, N, k, cap, descending, idx + q0 * k, val + q0 * k, todo_buf, force, qc, st);
+            else if (J <= 4) rc = launch_row_topk<4>(S, N, k, cap, descending, idx + q0 * k, val + q0 * k, todo_buf, force, qc, st);
+            else if (J <= 8) rc = launch_row_topk<8>(S, N, k, cap, descending, idx + q0 * k, val + q0 * k, todo_buf, force, qc, st);
+            else rc = launch_row_topk<16>(S, N, k, cap, descending, idx + q0 * k, val + q0 * k, todo_buf, force, qc, st);
+            if (rc != WV_OK) return rc;
+            todo = todo_buf;
         }
-        for (int p = 0; p < npass; ++p) {
-            src = (p & 1) ? bufA : bufB;
-            dst = (p & 1) ? bufB : bufA;
-            hipLaunchKernelGGL(k_radix_pass, dim3(qc), dim3(kRadixThreads), 0, st, S, src, dst, N, C, c_magic,
-                               p * kRadixBits, p == 0, p == npass - 1, k, descending, idx + q0 * k,
-                               val + q0 * k);
-        }
+        const int select_first = (int64_t)k * 2 <= N && !::wv::tune("WV_KNN_FULLSORT");
+        const int Ck = (int)ceil_div(k, kRadixThreads);
+        const uint32_t ck_magic = Ck <= 1 ? 0u : (uint32_t)(((1ull << 32) + Ck - 1) / Ck);
+        hipLaunchKernelGGL(k_row_radix, dim3(qc), dim3(kRadixThreads), 0, st, S, bufA, bufB, N, C, c_magic, k, Ck, ck_magic,
+                           select_first, descending, idx + q0 * k, val + q0 * k, todo);
     }
     WV_CHECK_LAUNCH("knn_float");
     return WV_OK;

@@ -1,0 +1,89 @@
+"""wv_knn_float's one-kernel ranking (k_row_topk: value bins -> LDS list -> in-bin ranks) against the radix kernel it
+replaces for k <= 15,360 and against the stable oracle.  Both rank the SAME fp32 score matrix (k_scores), so indices
+and values must be equal bit for bit -- ascending (key, index), ties by ascending index (get_knn.py:60-71 semantics:
+torch.topk's order inside a tie is implementation-defined; ours is the stable one)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ranking
+from wvhash import _lib
+from wvhash.engine.get_knn import knn_float
+
+pytestmark = pytest.mark.gpu
+
+IP, L2 = _lib.WV_METRIC_IP, _lib.WV_METRIC_L2
+
+
+def _pair(Q, N, D, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(Q, D, generator=g).cuda(), torch.randn(N, D, generator=g).cuda()
+
+
+def _both(diag, r, q, k, metric):
+    diag.delenv("WV_KNN_RADIX_ONLY", raising=False)
+    v1, i1 = knn_float(r, q, k, metric)
+    diag.setenv("WV_KNN_RADIX_ONLY", "1")
+    v0, i0 = knn_float(r, q, k, metric)
+    diag.delenv("WV_KNN_RADIX_ONLY")
+    torch.cuda.synchronize()
+    return (v1, i1), (v0, i0)
+
+
+@pytest.mark.parametrize("Q,N,D,k,metric", [
+    (64, 25000, 64, 5000, IP),        # the c1 shape
+    (33, 25000, 32, 100, L2),
+    (20, 5717, 16, 5717, IP),         # c0: k = N, every bin survives
+    (7, 117224, 8, 5000, L2),         # c3 row length
+    (9, 300, 8, 300, L2),             # shorter than the sample: range = exact min / max
+    (5, 4097, 8, 1, IP),              # one more than the sample, k = 1
+    (3, 70000, 4, 15360, L2),         # the largest k the LDS list takes
+    (3, 70000, 4, 15361, L2),         # one more: radix kernels only
+    (130, 1000, 12, 37, IP),
+    (4, 2, 4, 2, L2), (4, 1, 4, 1, IP),
+])
+def test_row_topk_equals_the_radix_kernels(diag, Q, N, D, k, metric):
+    q, r = _pair(Q, N, D, Q * 7 + N)
+    (v1, i1), (v0, i0) = _both(diag, r, q, k, metric)
+    assert torch.equal(i1, i0)
+    assert torch.equal(v1.view(torch.int32), v0.view(torch.int32))
+
+
+def test_rows_the_value_bins_cannot_take_are_handed_to_the_radix_kernels(diag):
+    """One call, rows of every kind: smooth scores, a constant row, a row with one huge outlier in the sample (all other
+    scores share a bin), a NaN row, integer-valued scores (ties en masse).  Equal to the radix kernels row by row."""
+    Q, N, D, k = 40, 9000, 8, 1200
+    q, r = _pair(Q, N, D, 5)
+    r[0] = 3e4                               # |q . r0| ~ 1e5: stretches the sampled range of every row
+    q[3] = 0.0                               # constant row (all scores 0)
+    q[4] = float("nan")
+    q[5:9] = torch.randint(-2, 3, (4, D), device="cuda").float()
+    r[100:4000] = torch.randint(-2, 3, (3900, D), device="cuda").float()
+    for metric in (IP, L2):
+        (v1, i1), (v0, i0) = _both(diag, r, q, k, metric)
+        assert torch.equal(i1, i0)
+        assert torch.equal(v1.view(torch.int32), v0.view(torch.int32))
+
+
+def test_forced_hand_over_of_every_row(diag):
+    q, r = _pair(50, 6000, 16, 11)
+    v1, i1 = knn_float(r, q, 700, IP)
+    diag.setenv("WV_KNN_FORCE_TODO", "1")
+    v2, i2 = knn_float(r, q, 700, IP)
+    torch.cuda.synchronize()
+    assert torch.equal(i1, i2) and torch.equal(v1, v2)
+
+
+@pytest.mark.parametrize("metric,name", [(IP, "cosine"), (L2, "l2")])
+def test_row_topk_against_the_stable_oracle(metric, name):
+    """Release library (no switches): integer-valued embeddings make every score exact in fp32, so the oracle's stable
+    ranking is the unique answer -- duplicated rows put ties on both sides of the k-th position."""
+    g = torch.Generator().manual_seed(3)
+    Q, N, D, k = 13, 6000, 8, 2500
+    q = torch.randint(-3, 4, (Q, D), generator=g).float()
+    r = torch.randint(-3, 4, (N, D), generator=g).float() + torch.arange(N).float()[:, None] % 7 * 0.125
+    r[N // 2:] = r[: N - N // 2].clone()
+    v, i = knn_float(r.cuda(), q.cuda(), k, metric)
+    sd, si = ranking.knn_stable(r, q, k, name)
+    assert torch.equal(i.cpu().long(), si.long())
+    np.testing.assert_allclose(v.cpu().numpy(), sd.numpy(), rtol=1e-6, atol=1e-6)
