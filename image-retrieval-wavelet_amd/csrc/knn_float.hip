@@ -9,8 +9,9 @@
 // k_scores: one wave owns a 64x64 tile of the [Q, N] score matrix as 2x2 blocks of
 //   v_mfma_f32_32x32x2_f32 (fp32 in / fp32 accumulate: bit-for-bit an fmaf chain, so no precision
 //   is traded for the matrix cores).  Lane l feeds row (l & 31) of A and of B; lane half h = l>>5
-//   covers k in [8c+4h, 8c+4h+4) of every 8-wide chunk with ONE float4 load per operand -- the MFMA
-//   sums over k, so any k <-> (step, half) bijection shared by A and B is valid.
+//   covers k in [8c+4h, 8c+4h+4) of every 8-wide chunk with ONE float4 per operand -- the MFMA
+//   sums over k, so any k <-> (step, half) bijection shared by A and B is valid.  Both operands are
+//   read from fragment images (k_pack_fragments) in which those 64 float4 are contiguous.
 // k_radix_pass: exact ranking of every row by 6 stable LSD counting-sort passes over the
 //   order-preserving 32-bit image of the float (ties therefore end in ascending index order),
 //   with the same private-column LDS histogram as the Hamming ranking kernel (topk.hip).
@@ -40,13 +41,94 @@ __global__ __launch_bounds__(256) void k_row_sqnorm(const float *__restrict__ x,
     if (lane == 0) out[row] = s;
 }
 
-// S[qi][n] = q[qi] . db[n]          (metric IP)
-//          = sqrt(max(0, |q|^2 + |db|^2 - 2 q.db))   (metric L2)
-__global__ __launch_bounds__(256) void k_scores(const float *__restrict__ q, const float *__restrict__ db,
-                                                const float *__restrict__ qn, const float *__restrict__ dbn,
-                                                float *__restrict__ S, int Q, int64_t N, int D, int metric)
+// Fragment image of an embedding matrix x [rows, D]: for every block of 32 rows and every chunk of 8 k-values the 64
+// float4 a wave feeds to four v_mfma_f32_32x32x2_f32 -- lane (r, h) holds x[32 rb + r][8c + 4h .. 8c + 4h + 4) -- lie in
+// lane order, 1 KB contiguous.  k_scores then reads each operand fragment with ONE fully coalesced load instruction
+// (the row-major matrix gave 32 B per row per instruction, a quarter of every line it pulled through L1: the operand
+// stream, not the matrix pipe, set its pace).  Rows beyond `rows` and k beyond D are zeros; a workgroup writes the four
+// chunks that share one 128-byte line of each source row.
+__global__ __launch_bounds__(256) void k_pack_fragments(const float *__restrict__ x, float4 *__restrict__ out,
+                                                        int64_t rows, int D, int nchunk, int64_t total)
 {
-    const int lane = lane_id(), wv = wave_id();
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;   // float4 index of the image
+    if (o >= total) return;
+    const int lane = (int)(o & 63);
+    const int64_t bc = o >> 6;
+    const int c = (int)(bc % nchunk);
+    const int64_t row = (bc / nchunk) * 32 + (lane & 31);
+    const int k = 8 * c + 4 * (lane >> 5);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < rows && k < D) v = *reinterpret_cast<const float4 *>(x + row * D + k);   // D % 4 == 0
+    out[o] = v;
+}
+
+// S[qi][n] = q[qi] . db[n]          (metric IP)
+//          = max(0, |q|^2 + |db|^2 - 2 q.db)         (metric L2: squared; the ranking kernels take the root of what they return)
+// i0 / j0 are wave-uniform (SGPRs): every store is a scalar row base + ONE per-lane offset (4h rows down, r columns in)
+template <bool L2>
+__device__ __forceinline__ void scores_store(const f32x16 (&acc)[2][2], float *__restrict__ S, const float *__restrict__ qn,
+                                             const float *__restrict__ dbn, int64_t i0, int64_t j0, int Q, int64_t N, int r,
+                                             int h, bool interior)
+{
+    float dn[2] = {0.f, 0.f};
+    if (L2) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) dn[b] = dbn[min(j0 + b * 32 + r, N - 1)];
+    }
+    const uint32_t voff = (uint32_t)(4 * h) * (uint32_t)N + (uint32_t)r;   // N <= 2^26: the byte offset fits 32 bits
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        // the norms are fetched with clamped indices, all sixteen loads in flight together (guarded loads would each wait
+        // for the one before); only edge tiles guard their stores
+        float qv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int64_t row = i0 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            qv[e] = L2 ? qn[min(row, (int64_t)Q - 1)] : 0.f;
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const bool col_ok = interior || j0 + b * 32 + r < N;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t row_u = i0 + a * 32 + (e & 3) + 8 * (e >> 2);          // uniform part of the row
+                float v = acc[a][b][e];
+                if (L2) v = fmaxf(0.f, fmaf(-2.f, v, qv[e] + dn[b]));   // squared: the root is taken of the k results only
+                float *base = S + row_u * N + (j0 + b * 32);
+                if (col_ok && (interior || row_u + 4 * h < Q)) base[voff] = v;
+            }
+        }
+    }
+}
+
+struct ScoreFrag {
+    float4 a[2], b[2];   // the 32-row blocks of the wave's 64 x 64 tile
+};
+
+__device__ __forceinline__ void scores_load(ScoreFrag &f, const float4 *const (&af)[2], const float4 *const (&bf)[2], int c)
+{
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        f.a[blk] = af[blk][(int64_t)c * 64];
+        f.b[blk] = bf[blk][(int64_t)c * 64];
+    }
+}
+
+__device__ __forceinline__ void scores_mma(f32x16 (&acc)[2][2], const ScoreFrag &f)
+{
+    // consecutive MFMAs go to different accumulators: a dependent pair is four instructions apart
+#define WV_SC_STEP(E)                                                                                   \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)         \
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[a].E, f.b[b].E, acc[a][b], 0, 0, 0);
+    WV_SC_STEP(x) WV_SC_STEP(y) WV_SC_STEP(z) WV_SC_STEP(w)
+#undef WV_SC_STEP
+}
+
+__global__ __launch_bounds__(256, 3) void k_scores(const float4 *__restrict__ qf, const float4 *__restrict__ dbf,
+                                                const float *__restrict__ qn, const float *__restrict__ dbn,
+                                                float *__restrict__ S, int Q, int64_t N, int nchunk, int metric)
+{
+    const int lane = lane_id(), wv = __builtin_amdgcn_readfirstlane(wave_id());
     const int r = lane & 31, h = lane >> 5;
     // 128x128 per workgroup, wave (wv>>1, wv&1) owns a 64x64 quadrant
     const int64_t i0 = (int64_t)blockIdx.y * 128 + (wv >> 1) * 64;
@@ -60,63 +142,155 @@ __global__ __launch_bounds__(256) void k_scores(const float *__restrict__ q, con
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    const float *arow[2], *brow[2];
+    // both images are padded to whole 128-row tiles, so every block a wave touches exists
+    const float4 *af[2], *bf[2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int64_t ia = min(i0 + a * 32 + r, (int64_t)Q - 1);  // clamp: extra rows are never stored
-        const int64_t jb = min(j0 + a * 32 + r, N - 1);
-        arow[a] = q + ia * D;
-        brow[a] = db + jb * D;
+    for (int blk = 0; blk < 2; ++blk) {
+        af[blk] = qf + ((i0 >> 5) + blk) * nchunk * 64 + lane;
+        bf[blk] = dbf + ((j0 >> 5) + blk) * nchunk * 64 + lane;
     }
-    const int Dfull = D & ~7;
-    for (int k = 0; k < Dfull; k += 8) {
-        float4 av[2], bv[2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            av[a] = *reinterpret_cast<const float4 *>(arow[a] + k + 4 * h);
-            bv[a] = *reinterpret_cast<const float4 *>(brow[a] + k + 4 * h);
-        }
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].x, bv[b].x, acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].y, bv[b].y, acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].z, bv[b].z, acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].w, bv[b].w, acc[a][b], 0, 0, 0);
-            }
+    // the fragments of chunk c + 1 are in flight while the 16 MFMAs of chunk c issue (pinned with sched_barrier: left
+    // alone, the scheduler sinks every load to its first use)
+    ScoreFrag f0, f1;
+    scores_load(f0, af, bf, 0);
+    int c = 0;
+    for (; c + 2 < nchunk; c += 2) {
+        scores_load(f1, af, bf, c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        scores_mma(acc, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        scores_load(f0, af, bf, c + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        scores_mma(acc, f1);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    for (int k = Dfull; k < D; k += 2) {  // tail: one k per lane half, zero beyond D
-        const int kk = k + h;
-        float a_[2], b_[2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            a_[a] = kk < D ? arow[a][kk] : 0.f;
-            b_[a] = kk < D ? brow[a][kk] : 0.f;
-        }
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[a], b_[b], acc[a][b], 0, 0, 0);
+    if (c + 1 < nchunk) {
+        scores_load(f1, af, bf, c + 1);
+        scores_mma(acc, f0);
+        scores_mma(acc, f1);
+    } else {
+        scores_mma(acc, f0);
     }
     // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const bool interior = i0 + 64 <= Q && j0 + 64 <= N;
+    if (metric != WV_METRIC_IP) scores_store<true>(acc, S, qn, dbn, i0, j0, Q, N, r, h, interior);
+    else scores_store<false>(acc, S, qn, dbn, i0, j0, Q, N, r, h, interior);
+}
+
+// The same tile with the operands shared through LDS: a 128 x 128 workgroup tile needs 4 + 4 row blocks per chunk, but the
+// four waves of k_scores fetch 2 + 2 each -- every fragment twice, 0.0625 B/flop from L2.  Here wave w fetches block w of
+// A and of B for a stage of four chunks (8 coalesced 1 KB loads, kept in registers while the previous stage computes),
+// stores them to one half of a double-buffered LDS ring, and every wave reads its 2 + 2 blocks back as ds_read_b128
+// (lane-contiguous: conflict-free).  One barrier per stage of 64 MFMAs.
+#ifndef WV_SC_STAGE
+#define WV_SC_STAGE 4
+#endif
+#ifndef WV_SC_WAVES
+#define WV_SC_WAVES 2
+#endif
+constexpr int kScStage = WV_SC_STAGE;                          // chunks of 8 k-values per stage
+constexpr int kScStageF4 = 2 * 4 * kScStage * 64;              // float4 per stage: (A, B) x 4 blocks x chunks x lanes
+
+__global__ __launch_bounds__(256, WV_SC_WAVES) void k_scores_lds(const float4 *__restrict__ qf, const float4 *__restrict__ dbf,
+                                                       const float *__restrict__ qn, const float *__restrict__ dbn,
+                                                       float *__restrict__ S, int Q, int64_t N, int nchunk, int metric)
+{
+    __shared__ float4 ring[2 * kScStageF4];                    // 64 KB
+    const int lane = lane_id(), wv = __builtin_amdgcn_readfirstlane(wave_id());
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t ti = (int64_t)blockIdx.y * 128, tj = (int64_t)blockIdx.x * 128;
+    const int wa = wv >> 1, wb = wv & 1;
+    const int64_t i0 = ti + wa * 64, j0 = tj + wb * 64;
+    f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int64_t col = j0 + b * 32 + r;
-            if (col >= N) continue;
-            const float dn = metric == WV_METRIC_L2 ? dbn[col] : 0.f;
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t row = i0 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row >= Q) continue;
-                float v = acc[a][b][e];
-                if (metric == WV_METRIC_L2) v = sqrtf(fmaxf(0.f, fmaf(-2.f, v, qn[row] + dn)));
-                S[row * N + col] = v;
-            }
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    // this wave's share of a stage: block wv of the A tile and of the B tile (the images are padded to whole tiles and
+    // to whole stages, so every fragment exists)
+    const float4 *ga = qf + ((ti >> 5) + wv) * nchunk * 64 + lane;
+    const float4 *gb = dbf + ((tj >> 5) + wv) * nchunk * 64 + lane;
+    float4 *la = ring + (wv * kScStage) * 64 + lane;                       // A[blk][cc][lane]
+    float4 *lb = ring + (4 * kScStage + wv * kScStage) * 64 + lane;        // B[blk][cc][lane]
+    const float4 *ra = ring + (2 * wa * kScStage) * 64 + lane;
+    const float4 *rb = ring + (4 * kScStage + 2 * wb * kScStage) * 64 + lane;
+    // (named registers, not arrays: carried around the loop, arrays of float4 were promoted to LDS / scratch by the compiler)
+    static_assert(kScStage == 4 || kScStage == 2, "the staging registers below are written out for two or four chunks");
+    float4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;
+#if WV_SC_STAGE == 4
+#define WV_SC_FETCH(OFF)                                                                                        \
+    pa0 = ga[(OFF)]; pb0 = gb[(OFF)]; pa1 = ga[(OFF) + 64]; pb1 = gb[(OFF) + 64];                               \
+    pa2 = ga[(OFF) + 128]; pb2 = gb[(OFF) + 128]; pa3 = ga[(OFF) + 192]; pb3 = gb[(OFF) + 192];
+#define WV_SC_STASH(DA, DB)                                                                                     \
+    (DA)[0] = pa0; (DB)[0] = pb0; (DA)[64] = pa1; (DB)[64] = pb1;                                               \
+    (DA)[128] = pa2; (DB)[128] = pb2; (DA)[192] = pa3; (DB)[192] = pb3;
+#else
+#define WV_SC_FETCH(OFF) pa0 = ga[(OFF)]; pb0 = gb[(OFF)]; pa1 = ga[(OFF) + 64]; pb1 = gb[(OFF) + 64];
+#define WV_SC_STASH(DA, DB) (DA)[0] = pa0; (DB)[0] = pb0; (DA)[64] = pa1; (DB)[64] = pb1;
+    (void)pa2; (void)pa3; (void)pb2; (void)pb3;
+#endif
+    const int nstage = nchunk / kScStage;
+    WV_SC_FETCH((int64_t)0)
+    WV_SC_STASH(la, lb)
+    {
+        const int64_t one = (int64_t)min(1, nstage - 1) * kScStage * 64;
+        WV_SC_FETCH(one)
+    }
+    __syncthreads();
+    // Staging pipeline (one register set): stage st + 1 travels global -> registers during stage st - 1's MFMAs, is
+    // written to the free half of the ring at the START of stage st (that half was last read before the barrier that
+    // ended stage st - 1), and the registers are re-issued for stage st + 2 at once: every load has a whole stage of
+    // MFMAs to land and cannot be sunk to its use, which is an iteration away.  Refills are unconditional (the last
+    // stages fetch the final stage again and store it where nobody reads: a conditional refill costs a vmcnt(0) per load).
+    for (int st = 0; st < nstage; ++st) {
+        const int buf = st & 1;
+        {
+            float4 *da = la + (buf ^ 1) * kScStageF4, *db_ = lb + (buf ^ 1) * kScStageF4;
+            WV_SC_STASH(da, db_)
+            const int64_t nxt = (int64_t)min(st + 2, nstage - 1) * kScStage * 64;
+            WV_SC_FETCH(nxt)
         }
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 *sa = ra + buf * kScStageF4, *sb = rb + buf * kScStageF4;
+        ScoreFrag f0, f1;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            f0.a[blk] = sa[(blk * kScStage + 0) * 64];
+            f0.b[blk] = sb[(blk * kScStage + 0) * 64];
+        }
+#pragma unroll
+        for (int cc = 0; cc < kScStage; cc += 2) {
+            // the next chunk's fragments are read before this chunk's MFMAs issue (pinned: the scheduler sinks them otherwise)
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                f1.a[blk] = sa[(blk * kScStage + cc + 1) * 64];
+                f1.b[blk] = sb[(blk * kScStage + cc + 1) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            scores_mma(acc, f0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (cc + 2 < kScStage) {
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    f0.a[blk] = sa[(blk * kScStage + cc + 2) * 64];
+                    f0.b[blk] = sb[(blk * kScStage + cc + 2) * 64];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            scores_mma(acc, f1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+#undef WV_SC_FETCH
+#undef WV_SC_STASH
+    if (i0 >= Q || j0 >= N) return;
+    const bool interior = i0 + 64 <= Q && j0 + 64 <= N;
+    if (metric != WV_METRIC_IP) scores_store<true>(acc, S, qn, dbn, i0, j0, Q, N, r, h, interior);
+    else scores_store<false>(acc, S, qn, dbn, i0, j0, Q, N, r, h, interior);
 }
 
 __device__ __forceinline__ uint32_t float_to_key(float v, bool descending)
@@ -142,8 +316,8 @@ __device__ __forceinline__ float key_to_float(uint32_t u, bool descending)
 // leaves its workgroup, so the passes need a barrier between them, not a kernel boundary)
 __device__ __forceinline__ void radix_pass(uint32_t *hist, uint32_t *tot, uint32_t *base, const float *__restrict__ S,
                                            const uint2 *src, uint2 *dst, int64_t N, int C, uint32_t c_magic, int shift,
-                                           int first, int last, int k, int descending, int32_t *__restrict__ idx_out,
-                                           float *__restrict__ val_out)
+                                           int first, int last, int k, int descending, int sqrt_out,
+                                           int32_t *__restrict__ idx_out, float *__restrict__ val_out)
 {
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     const int64_t row = blockIdx.x;
@@ -207,7 +381,8 @@ __device__ __forceinline__ void radix_pass(uint32_t *hist, uint32_t *tot, uint32
         if (last) {
             if (pos < (uint32_t)k) {
                 idx_out[row * k + pos] = (int32_t)kv.y;
-                val_out[row * k + pos] = key_to_float(kv.x, descending);
+                const float v = key_to_float(kv.x, descending);
+                val_out[row * k + pos] = sqrt_out ? sqrtf(v) : v;
             }
         } else {
             const uint32_t tq = C == 1 ? pos : __umulhi(pos, c_magic);   // pos / C
@@ -324,7 +499,8 @@ __device__ __forceinline__ void select_compact(uint32_t *hist, uint32_t *wpart, 
 __global__ __launch_bounds__(kRadixThreads) void k_row_radix(const float *__restrict__ S, uint2 *bufA, uint2 *bufB,
                                                              int64_t N, int C, uint32_t c_magic, int k, int Ck,
                                                              uint32_t ck_magic, int select_first, int descending,
-                                                             int32_t *__restrict__ idx_out, float *__restrict__ val_out,
+                                                             int sqrt_out, int32_t *__restrict__ idx_out,
+                                                             float *__restrict__ val_out,
                                                              const uint8_t *__restrict__ todo)
 {
     if (todo && !todo[blockIdx.x]) return;
@@ -338,12 +514,12 @@ __global__ __launch_bounds__(kRadixThreads) void k_row_radix(const float *__rest
         __syncthreads();
         for (int p = 0; p < npass; ++p)
             radix_pass(hist, tot, base, S, (p & 1) ? bufA : bufB, (p & 1) ? bufB : bufA, (int64_t)k, Ck, ck_magic,
-                       p * kRadixBits, 0, p == npass - 1, k, descending, idx_out, val_out);
+                       p * kRadixBits, 0, p == npass - 1, k, descending, sqrt_out, idx_out, val_out);
         return;
     }
     for (int p = 0; p < npass; ++p)
         radix_pass(hist, tot, base, S, (p & 1) ? bufA : bufB, (p & 1) ? bufB : bufA, N, C, c_magic, p * kRadixBits,
-                   p == 0, p == npass - 1, k, descending, idx_out, val_out);
+                   p == 0, p == npass - 1, k, descending, sqrt_out, idx_out, val_out);
 }
 
 // ---- one kernel per row for k <= 15,360: the list is selected, sorted and written without leaving the CU ----------
@@ -401,7 +577,7 @@ template <int JMAX>
 __global__ __launch_bounds__(kTkThreads) void k_row_topk(const float *__restrict__ S, int64_t N, int k, int cap,
                                                          int descending, int32_t *__restrict__ idx_out,
                                                          float *__restrict__ val_out, uint8_t *__restrict__ todo,
-                                                         int force_radix)
+                                                         int force_radix, int sqrt_out)
 {
     extern __shared__ uint4 tk_sm4[];
     uint32_t *cursor = reinterpret_cast<uint32_t *>(tk_sm4);   // [4096] counts -> exclusive prefix -> running cursor
@@ -558,13 +734,14 @@ __global__ __launch_bounds__(kTkThreads) void k_row_topk(const float *__restrict
     for (int i = tid; i < k; i += kTkThreads) {
         const uint64_t e = A[i];
         idx_out[row * k + i] = (int32_t)(uint32_t)e;
-        val_out[row * k + i] = key_to_float((uint32_t)(e >> 32), desc);
+        const float v = key_to_float((uint32_t)(e >> 32), desc);
+        val_out[row * k + i] = sqrt_out ? sqrtf(v) : v;
     }
 }
 
 template <int JMAX>
 static int launch_row_topk(const float *S, int64_t N, int k, int cap, int descending, int32_t *idx, float *val,
-                           uint8_t *todo, int force_radix, int rows, hipStream_t st)
+                           uint8_t *todo, int force_radix, int sqrt_out, int rows, hipStream_t st)
 {
     const size_t lds = tk_lds_bytes(cap);
     auto kern = k_row_topk<JMAX>;
@@ -574,7 +751,7 @@ static int launch_row_topk(const float *S, int64_t N, int k, int cap, int descen
         if (e != hipSuccess) WV_FAIL(WV_EHIP, "knn_float: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3(kTkThreads), lds, st, S, N, k, cap, descending, idx, val, todo,
-                       force_radix);
+                       force_radix, sqrt_out);
     return WV_OK;
 }
 
@@ -593,11 +770,12 @@ using namespace wv;
 
 extern "C" size_t wv_knn_float_workspace_bytes(int Q, int64_t N, int D, int k)
 {
-    (void)D; (void)k;
+    (void)k;
     if (Q <= 0 || N <= 0) return 0;
     const int64_t rows = knn_chunk_rows(Q, N);
     const int64_t pitch = ceil_div(N, kRadixThreads) * kRadixThreads;
-    return (size_t)(rows * (N * 4 + pitch * 16) + (align_up(Q, 64) + align_up(N, 64)) * 4 + align_up(rows, 256) + 1024);
+    return (size_t)(rows * (N * 4 + pitch * 16) + (align_up(Q, 64) + align_up(N, 64)) * 4 + align_up(rows, 256) +
+                    (align_up(rows, 128) + align_up(N, 128)) * align_up(D, 8 * kScStage) * 4 + 1024);
 }
 
 extern "C" int wv_knn_float(const float *q, const float *db, int Q, int64_t N, int D, int metric, int k,
@@ -606,7 +784,8 @@ extern "C" int wv_knn_float(const float *q, const float *db, int Q, int64_t N, i
 {
     WV_REQUIRE(q && db && idx && val, "knn_float: null buffer");
     WV_REQUIRE(Q >= 0 && N >= 1 && D >= 1, "knn_float: bad shape Q=%d N=%lld D=%d", Q, (long long)N, D);
-    WV_REQUIRE(metric == WV_METRIC_IP || metric == WV_METRIC_L2, "knn_float: metric %d", metric);
+    WV_REQUIRE(metric == WV_METRIC_IP || metric == WV_METRIC_L2 || metric == WV_METRIC_L2_SQUARED, "knn_float: metric %d",
+               metric);
     WV_REQUIRE(k >= 1 && k <= N, "knn_float: k=%d must be in [1, N=%lld] (torch.topk raises too)", k,
                (long long)N);
     WV_REQUIRE(N <= (1ll << 26), "knn_float: N=%lld above the supported 2^26 rows", (long long)N);
@@ -624,18 +803,34 @@ extern "C" int wv_knn_float(const float *q, const float *db, int Q, int64_t N, i
     uint2 *bufB = (uint2 *)w;              w += rows * pitch * 8;
     float *qn = (float *)w;                w += align_up(Q, 64) * 4;
     float *dbn = (float *)w;               w += align_up(N, 64) * 4;
-    uint8_t *todo_buf = (uint8_t *)w;      // [rows] 1 = k_row_topk left the row to the radix kernels
-    if (metric == WV_METRIC_L2) {
+    uint8_t *todo_buf = (uint8_t *)w;      w += align_up(rows, 256);   // [rows] 1 = k_row_topk left the row to the radix kernel
+    const int nchunk = (int)align_up(ceil_div(D, 8), kScStage);   // chunks of 8 k-values, whole stages (zero-padded)
+    // fragment images, padded to whole 128-row tiles: the database once, the queries of a chunk per chunk
+    float4 *qf = (float4 *)w;              w += align_up(rows, 128) * nchunk * 32;   // bytes: rows * nchunk * 8 floats
+    float4 *dbf = (float4 *)w;
+    {
+        const int64_t tn = align_up(N, 128) / 32 * nchunk * 64;
+        hipLaunchKernelGGL(k_pack_fragments, dim3((unsigned)ceil_div(tn, 256)), dim3(256), 0, st, db, dbf, N, D, nchunk, tn);
+    }
+    if (metric != WV_METRIC_IP) {
         hipLaunchKernelGGL(k_row_sqnorm, dim3((unsigned)ceil_div(Q, 4)), dim3(256), 0, st, q, (int64_t)Q, D, qn);
         hipLaunchKernelGGL(k_row_sqnorm, dim3((unsigned)ceil_div(N, 4)), dim3(256), 0, st, db, N, D, dbn);
     }
     const int C = (int)ceil_div(N, kRadixThreads);
     const uint32_t c_magic = C <= 1 ? 0u : (uint32_t)(((1ull << 32) + C - 1) / C);   // exact for pos < 2^32 / C
     const int descending = metric == WV_METRIC_IP;
+    const int sqrt_out = metric == WV_METRIC_L2;   // L2 rows are ranked on SQUARED distances (what faiss ranks on; the same
+                                                   // order up to ties the rounding of the root creates); the k results get the root
     for (int64_t q0 = 0; q0 < Q; q0 += rows) {
         const int qc = (int)std::min<int64_t>(rows, Q - q0);
         dim3 grid((unsigned)ceil_div(N, 128), (unsigned)ceil_div(qc, 128));
-        hipLaunchKernelGGL(k_scores, grid, dim3(256), 0, st, q + q0 * D, db, qn + q0, dbn, S, qc, N, D, metric);
+        const int64_t tq = align_up(qc, 128) / 32 * nchunk * 64;
+        hipLaunchKernelGGL(k_pack_fragments, dim3((unsigned)ceil_div(tq, 256)), dim3(256), 0, st, q + q0 * D, qf, (int64_t)qc, D,
+                           nchunk, tq);
+        if (::wv::tune("WV_KNN_SCORES_DIRECT"))
+            hipLaunchKernelGGL(k_scores, grid, dim3(256), 0, st, qf, dbf, qn + q0, dbn, S, qc, N, nchunk, metric);
+        else
+            hipLaunchKernelGGL(k_scores_lds, grid, dim3(256), 0, st, qf, dbf, qn + q0, dbn, S, qc, N, nchunk, metric);
         // rows the one-kernel ranking takes never reach the radix kernels (they return at once on todo[row] == 0)
         const uint8_t *todo = nullptr;
         if (k + kTkSlack <= kTkCapMax && !::wv::tune("WV_KNN_RADIX_ONLY")) {
@@ -644,10 +839,10 @@ extern "C" int wv_knn_float(const float *q, const float *db, int Q, int64_t N, i
             if (const char *stop = ::wv::tune("WV_TK_STOP")) force |= atoi(stop) << 8;
             const int J = cap / kTkThreads;
             int rc;
-            if (J <= 2) rc = launch_row_topk<2>(S, N, k, cap, descending, idx + q0 * k, val + q0 * k, todo_buf, force, qc, st);
-            else if (J <= 4) rc = launch_row_topk<4>(S, N, k, cap, descending, idx + q0 * k, val + q0 * k, todo_buf, force, qc, st);
-            else if (J <= 8) rc = launch_row_topk<8>(S, N, k, cap, descending, idx + q0 * k, val + q0 * k, todo_buf, force, qc, st);
-            else rc = launch_row_topk<16>(S, N, k, cap, descending, idx + q0 * k, val + q0 * k, todo_buf, force, qc, st);
+            if (J <= 2) rc = launch_row_topk<2>(S, N, k, cap, descending, idx + q0 * k, val + q0 * k, todo_buf, force, sqrt_out, qc, st);
+            else if (J <= 4) rc = launch_row_topk<4>(S, N, k, cap, descending, idx + q0 * k, val + q0 * k, todo_buf, force, sqrt_out, qc, st);
+            else if (J <= 8) rc = launch_row_topk<8>(S, N, k, cap, descending, idx + q0 * k, val + q0 * k, todo_buf, force, sqrt_out, qc, st);
+            else rc = launch_row_topk<16>(S, N, k, cap, descending, idx + q0 * k, val + q0 * k, todo_buf, force, sqrt_out, qc, st);
             if (rc != WV_OK) return rc;
             todo = todo_buf;
         }
@@ -655,7 +850,7 @@ extern "C" int wv_knn_float(const float *q, const float *db, int Q, int64_t N, i
         const int Ck = (int)ceil_div(k, kRadixThreads);
         const uint32_t ck_magic = Ck <= 1 ? 0u : (uint32_t)(((1ull << 32) + Ck - 1) / Ck);
         hipLaunchKernelGGL(k_row_radix, dim3(qc), dim3(kRadixThreads), 0, st, S, bufA, bufB, N, C, c_magic, k, Ck, ck_magic,
-                           select_first, descending, idx + q0 * k, val + q0 * k, todo);
+                           select_first, descending, sqrt_out, idx + q0 * k, val + q0 * k, todo);
     }
     WV_CHECK_LAUNCH("knn_float");
     return WV_OK;

@@ -18,7 +18,7 @@ DIAG_LIB_PATH = os.path.join(_HERE, "_lib", "libwvhash_diag.so")
 
 WV_DT_U8, WV_DT_F32, WV_DT_BF16 = 0, 1, 2
 WV_LAYOUT_NCHW, WV_LAYOUT_NHWC = 0, 1
-WV_METRIC_IP, WV_METRIC_L2 = 0, 1
+WV_METRIC_IP, WV_METRIC_L2, WV_METRIC_L2_SQUARED = 0, 1, 2
 WV_BANDS_INNER, WV_BANDS_OUTER = 0, 1
 
 

@@ -72,9 +72,9 @@ def get_knn(references, queries, num_k, embeddings_come_from_same_source, with_f
         distances, idx = knn_float(references, queries, num_k, _lib.WV_METRIC_IP)
         indices = idx.long()
     else:
-        distances, idx = knn_float(references, queries, num_k, _lib.WV_METRIC_L2)
-        if with_faiss:                       # IndexFlatL2.search returns squared L2 (get_knn.py:38-39,55)
-            distances = distances * distances
+        # IndexFlatL2.search returns squared L2 (get_knn.py:38-39,55), torch.cdist the root (:67-69); same neighbours
+        distances, idx = knn_float(references, queries, num_k,
+                                   _lib.WV_METRIC_L2_SQUARED if with_faiss else _lib.WV_METRIC_L2)
         indices = idx.long()
 
     if embeddings_come_from_same_source:

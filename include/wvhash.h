@@ -311,11 +311,15 @@ int wv_hit_prefix(const int32_t *idx, int Q, int k, const uint64_t *qlab, const 
 /* ------------------------------------------------------------------------------------------
  * Real-valued k-NN (non-binary embeddings).  Replaces get_knn_torch (get_knn.py:60-71):
  *   metric 0: scores = q @ r.T,           top-k largest  (hamming / cosine branch)
- *   metric 1: d = torch.cdist(q, r, p=2), top-k smallest (true L2, not faiss' squared L2)
- * Ties are broken by ascending database index.  idx int32 [Q][k], val float32 [Q][k].
+ *   metric 1: d = torch.cdist(q, r, p=2), top-k smallest (true L2)
+ *   metric 2: the same neighbours with faiss IndexFlatL2's SQUARED distances (get_knn.py:38-39,55)
+ * L2 rows are ranked on the squared distance |q|^2 + |r|^2 - 2 q.r (clamped at 0) -- what faiss ranks on, and
+ * torch.cdist's order up to the ties the rounding of the root creates; metric 1 takes the root of the k results.
+ * Ties are broken by ascending database index.  idx int32 [Q][k], val float32 [Q][k].  D % 4 == 0, N <= 2^26.
  * ------------------------------------------------------------------------------------------ */
 #define WV_METRIC_IP 0
 #define WV_METRIC_L2 1
+#define WV_METRIC_L2_SQUARED 2
 size_t wv_knn_float_workspace_bytes(int Q, int64_t N, int D, int k);
 int wv_knn_float(const float *q, const float *db, int Q, int64_t N, int D, int metric, int k,
                  int32_t *idx, float *val, void *workspace, size_t workspace_bytes, void *stream);

@@ -87,3 +87,27 @@ def test_row_topk_against_the_stable_oracle(metric, name):
     sd, si = ranking.knn_stable(r, q, k, name)
     assert torch.equal(i.cpu().long(), si.long())
     np.testing.assert_allclose(v.cpu().numpy(), sd.numpy(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("D", [4, 12, 16, 20, 36, 52, 100, 384])
+def test_scores_are_exact_for_every_tail_of_the_k_loop(D):
+    """k_scores walks k in chunks of 16 with a two-stage register pipeline; the last chunk may hold 4, 8 or 12 values.
+    Integer-valued embeddings: every product and partial sum is exact in fp32, whatever the summation order, so the
+    sorted scores must equal torch's exactly -- on edge tiles too (Q, N not multiples of 64)."""
+    g = torch.Generator().manual_seed(D)
+    Q, N = 130, 333
+    q = torch.randint(-3, 4, (Q, D), generator=g).float()
+    r = torch.randint(-3, 4, (N, D), generator=g).float()
+    v, i = knn_float(r.cuda(), q.cuda(), N, IP)
+    full = q @ r.t()
+    assert torch.equal(torch.gather(full, 1, i.cpu().long()), v.cpu())
+    assert torch.equal(v.cpu(), torch.sort(full, dim=1, descending=True).values)
+    v2, i2 = knn_float(r.cuda(), q.cuda(), N, L2)
+    d2 = ((q[:, None, :] - r[None, :, :]) ** 2).sum(-1)
+    torch.testing.assert_close(v2.cpu(), torch.gather(d2, 1, i2.cpu().long()).sqrt(), rtol=3e-7, atol=0)   # sqrt: 1 ulp
+    assert (v2[:, 1:] >= v2[:, :-1]).all()
+    # metric 2 (faiss IndexFlatL2): the same neighbours, squared distances -- exact here, ties by ascending index
+    v3, i3 = knn_float(r.cuda(), q.cuda(), N, _lib.WV_METRIC_L2_SQUARED)
+    assert torch.equal(i3, i2)
+    order = torch.argsort(d2, dim=1, stable=True)
+    assert torch.equal(i3.cpu().long(), order) and torch.equal(v3.cpu(), torch.gather(d2, 1, order))

@@ -48,6 +48,7 @@ if __name__ == "__main__":
         (5000, 117224, 384, 5000, _lib.WV_METRIC_L2, "c3 L2 k=5000"),
         (2048, 25000, 64, 5000, _lib.WV_METRIC_IP, "c1 IP k=5000 D=64 (tanh codes)"),
     ]
+    exact = any(only == c[5] for c in cases)
     for c in cases:
-        if only in c[5]:
+        if (only == c[5]) if exact else (only in c[5]):
             case(*c)
