@@ -544,7 +544,7 @@ def extra_rows(p, reps):
         # ---- float k-NN (get_knn cosine / l2 path of non-hashing models): 2048 x 25,000, D = 384, k = 5000
         g = torch.Generator().manual_seed(7)
         qf, rf = torch.randn(p.Q, EMBED, generator=g).to(dev), torch.randn(N_DB, EMBED, generator=g).to(dev)
-        add(f"wv_knn_float[{p.Q} x {N_DB}, D={EMBED}, IP, k={TOPK}: fp32 MFMA scores + radix ranking] (not in the step)",
+        add(f"wv_knn_float[{p.Q} x {N_DB}, D={EMBED}, IP, k={TOPK}: fp32 MFMA scores + one-kernel value-bin ranking] (not in the step)",
             "mfma", 2 * p.Q * N_DB * EMBED, lambda: knn_float(rf, qf, TOPK, _lib.WV_METRIC_IP), max(2, reps // 2))
         del qf, rf
         # ---- the pipeline with a consumer (SURVEY 8(d) metric 3, f-1): raw u8 batch -> SWT (bf16, band-major, kernel-written) ->
