@@ -111,3 +111,24 @@ def test_scores_are_exact_for_every_tail_of_the_k_loop(D):
     assert torch.equal(i3, i2)
     order = torch.argsort(d2, dim=1, stable=True)
     assert torch.equal(i3.cpu().long(), order) and torch.equal(v3.cpu(), torch.gather(d2, 1, order))
+
+
+def test_query_chunks_of_a_long_database(diag):
+    """3,000,000 rows: the 2 GiB score scratch holds 35 query rows, so 40 queries take two chunks (the fragment image of the
+    queries is rebuilt per chunk, the hand-over flags are per chunk).  Integer-valued embeddings: exact scores, the stable
+    order is the unique answer."""
+    g = torch.Generator().manual_seed(1)
+    Q, N, D, k = 40, 3_000_000, 4, 50
+    q = torch.randint(-3, 4, (Q, D), generator=g).float().cuda()
+    r = torch.randint(-3, 4, (N, D), generator=g).float().cuda()
+    r[torch.randint(0, N, (200,), generator=g)] *= 5.0        # a few large scores so that the top k is not one tie bucket
+    v, i = knn_float(r, q, k, IP)
+    full = q @ r.t()
+    order = torch.argsort(-full, dim=1, stable=True)[:, :k]
+    assert torch.equal(i.long(), order)
+    assert torch.equal(v, torch.gather(full, 1, order))
+    del full, order
+    # smooth scores (the value-bin kernel takes every row) against the radix kernel, same two chunks
+    q, r = torch.randn(Q, D, generator=g).cuda(), torch.randn(N, D, generator=g).cuda()
+    (v1, i1), (v0, i0) = _both(diag, r, q, k, L2)
+    assert torch.equal(i1, i0) and torch.equal(v1.view(torch.int32), v0.view(torch.int32))
