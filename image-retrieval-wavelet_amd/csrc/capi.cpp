@@ -18,4 +18,4 @@ void set_error(const char *fmt, ...)
 }  // namespace wv
 
 extern "C" const char *wv_last_error(void) { return wv::g_err; }
-extern "C" int wv_abi_version(void) { return 4; }
+extern "C" int wv_abi_version(void) { return 5; }

@@ -105,6 +105,9 @@ SIGNATURES = {
     "wv_band_attn_prepare": (_i, [ctypes.POINTER(HeadParams), _vp, _vp]),
     "wv_band_attn_pool": (_i, [ctypes.POINTER(HeadParams), _vp, _i, _vp, _vp, _sz, _vp]),
     "wv_hash_tail": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),
+    "wv_knn_float_cpu": (_i, [_vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp]),
+    "wv_band_attn_pool_cpu": (_i, [ctypes.POINTER(HeadParams), _vp, _i, _vp]),
+    "wv_hash_tail_cpu": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
 }
 
 _LIB = None

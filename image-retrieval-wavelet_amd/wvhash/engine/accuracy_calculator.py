@@ -380,18 +380,25 @@ class CustomCalculator(object):
         return result
 
     def _host_knn(self, reference, query, num_k, same_source):
-        """get_knn (get_knn.py:9-24) on the host: +-1 codes under the hamming metric (what the hashing configs evaluate)."""
+        """get_knn (get_knn.py:9-24) on the host: +-1 codes under the hamming metric through the packed twins, everything
+        else through wv_knn_float_cpu -- the same lists and values as the GPU path in both cases."""
+        from .get_knn import knn_float_host
         num_k += int(same_source)
         nbits = reference.shape[1]
-        if not (self.distance_metric == "hamming" and nbits <= 128 and _is_pm1(reference) and _is_pm1(query)):
-            raise _lib.WvhashUnavailable("device='cpu' covers +-1 codes under distance_metric='hamming'; float k-NN "
-                                         "(cosine / l2) runs on the GPU (device=None)")
         if num_k > reference.shape[0]:
             raise RuntimeError(f"selected index k out of range (k={num_k}, references={reference.shape[0]})")
-        idx, dist = HH.hamming_topk(HH.pack_codes(query, check=False), HH.pack_codes(reference, check=False), nbits, num_k)
-        ip = float(nbits) - 2.0 * dist.float()
         first = int(same_source)
-        return idx[:, first:].long(), ip[:, first:]
+        if self.distance_metric == "hamming" and nbits <= 128 and _is_pm1(reference) and _is_pm1(query):
+            idx, dist = HH.hamming_topk(HH.pack_codes(query, check=False), HH.pack_codes(reference, check=False), nbits, num_k)
+            return idx[:, first:].long(), (float(nbits) - 2.0 * dist.float())[:, first:]
+        if nbits % 4:
+            raise _lib.WvhashUnavailable(f"float k-NN needs an embedding dimension that is a multiple of 4 (got {nbits})")
+        if self.distance_metric in ("hamming", "cosine"):
+            metric = _lib.WV_METRIC_IP
+        else:                                   # faiss IndexFlatL2 returns squared distances, torch.cdist the root
+            metric = _lib.WV_METRIC_L2_SQUARED if self.with_faiss else _lib.WV_METRIC_L2
+        val, idx = knn_float_host(reference, query, num_k, metric)
+        return idx[:, first:].long(), val[:, first:]
 
     def _get_accuracy(self, function_dict, **kwargs):
         return {k: v(**kwargs) for k, v in function_dict.items()}

@@ -51,6 +51,23 @@ def knn_float(references, queries, num_k, metric):
     return val, idx
 
 
+def knn_float_host(references, queries, num_k, metric):
+    """wv_knn_float's host twin (csrc/host_knn.cpp) on CPU tensors: the same indices and values as the GPU path, bit for
+    bit (the matrix cores' fp32 accumulation is an fmaf chain, which the twin walks in the same order)."""
+    lib = _lib.load()
+    q = queries.detach().float().contiguous()
+    r = references.detach().float().contiguous()
+    if q.is_cuda or r.is_cuda:
+        raise ValueError("knn_float_host takes host tensors")
+    Q, D = q.shape
+    N = r.shape[0]
+    idx = torch.empty((Q, num_k), dtype=torch.int32)
+    val = torch.empty((Q, num_k), dtype=torch.float32)
+    rc = lib.wv_knn_float_cpu(_lib.ptr(q), _lib.ptr(r), Q, N, D, metric, num_k, _lib.ptr(idx), _lib.ptr(val))
+    _lib.check(rc, "wv_knn_float_cpu")
+    return val, idx
+
+
 def get_knn(references, queries, num_k, embeddings_come_from_same_source, with_faiss=True, distance_metric="l2"):
     num_k += embeddings_come_from_same_source
 

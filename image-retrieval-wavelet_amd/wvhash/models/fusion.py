@@ -93,6 +93,32 @@ def band_attn_pool(features_list, q_eff, attn, norm1, norm2, mlp0, mlp2, out_pro
     return out
 
 
+def band_attn_pool_host(features_list, q_eff, attn, norm1, norm2, mlp0, mlp2, out_proj, pool_mean=False):
+    """The same forward on HOST tensors through the library's host twin (wv_band_attn_pool_cpu, csrc/host_head.cpp): for a
+    model that was moved to the CPU on purpose.  fp32, machine-independent summation order; agrees with the kernels to
+    fp32 rounding."""
+    lib = _lib.load()
+    feats = torch.stack([f.detach().float() for f in features_list], dim=0).contiguous()        # [S, B, E]
+    S, B, E = feats.shape
+    q_eff = q_eff.detach().float().reshape(-1, E).contiguous()
+    keep = [t.detach().float().contiguous() for t in
+            (q_eff, attn.in_proj_weight, attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias, norm1.weight, norm1.bias,
+             mlp0.weight, mlp0.bias, mlp2.weight, mlp2.bias, out_proj.weight, out_proj.bias, norm2.weight, norm2.bias)]
+    if any(t.is_cuda for t in keep) or feats.is_cuda:
+        raise ValueError("band_attn_pool_host takes host tensors (features and parameters)")
+    p = _lib.HeadParams()
+    p.embed_dim, p.num_heads, p.num_queries, p.num_tokens = E, attn.num_heads, q_eff.shape[0], S
+    p.pool_mean = 1 if pool_mean else 0
+    (p.q_eff, p.in_proj_w, p.in_proj_b, p.attn_out_w, p.attn_out_b, p.norm1_w, p.norm1_b, p.mlp0_w, p.mlp0_b,
+     p.mlp2_w, p.mlp2_b, p.out_w, p.out_b, p.norm2_w, p.norm2_b) = [t.data_ptr() for t in keep]
+    p.ln_eps = float(norm1.eps)
+    p.q_proj = None
+    p.prepared = None
+    out = torch.empty((B, E), dtype=torch.float32)
+    _lib.check(lib.wv_band_attn_pool_cpu(ctypes.byref(p), _lib.ptr(feats), B, _lib.ptr(out)), "wv_band_attn_pool_cpu")
+    return out
+
+
 class CrossAttentionBottleneckHeadAdvanced(nn.Module):
     _pool = "concat"
 
@@ -159,10 +185,23 @@ class CrossAttentionBottleneckHeadAdvanced(nn.Module):
     def forward(self, features_list):
         batch_size = features_list[0].shape[0]
         device = features_list[0].device
-        if not features_list[0].is_cuda and not self.training:
-            raise _lib.WvhashUnavailable("the eval-mode fusion head runs on the GPU only (no CPU path in wvhash); the "
-                                         "training-mode forward is stock PyTorch and follows its tensors' device")
         kv_list = [proj(f) for proj, f in zip(self.projections, features_list)]
+        if not features_list[0].is_cuda and not self.training:
+            # host tensors: never a silent fallback -- only after an explicit `head.host_twin = True` (a model meant to run
+            # on the CPU) does the library's host twin take the eval-mode forward (same math, fp32)
+            if not getattr(self, "host_twin", False):
+                raise _lib.WvhashUnavailable("the eval-mode fusion head runs on the GPU; for a model that is meant to run on "
+                                             "the host set `head.host_twin = True` (wv_band_attn_pool_cpu) -- there is no "
+                                             "silent CPU fallback.  The training-mode forward is stock PyTorch and follows "
+                                             "its tensors' device")
+            if (self.use_all_tokens or len(kv_list) > 64 or any(t.dim() != 2 for t in kv_list)
+                    or self.norm1.normalized_shape[0] % 8 or next(self.parameters()).is_cuda):
+                raise _lib.WvhashUnavailable("the eval-mode fusion head on host tensors covers CLS-token inputs ([B, E] per "
+                                             "band, E a multiple of 8, at most 64 bands) of a model that lives on the host")
+            self.last_ortho_loss = torch.zeros(())
+            with torch.no_grad():
+                return band_attn_pool_host(kv_list, self.effective_queries(), self.attn, self.norm1, self.norm2,
+                                           self.mlp[0], self.mlp[2], self.out_proj, self._pool == "mean")
 
         if self._hip_ok(kv_list):
             # torch.zeros launches a fill on the stream; torch.tensor(0.0, device=...) is a blocking host-to-device

@@ -32,9 +32,11 @@ def load_dinov2(name, retries=1, **kwargs):
                        "backbone=<nn.Module with .embed_dim> instead")
 
 
-def hash_tail(fused, hash_fc, bn, want=("codes",)):
-    """HIP tail: logits = hash_fc(fused); bn (eval); sign; pack.  -> dict of requested outputs."""
-    lib = _lib.require_gpu()
+def hash_tail(fused, hash_fc, bn, want=("codes",), host_twin=False):
+    """HIP tail: logits = hash_fc(fused); bn (eval); sign; pack.  -> dict of requested outputs.
+    host_twin=True (explicit; never a silent fallback): host tensors take the library's host twin wv_hash_tail_cpu."""
+    host = bool(host_twin) and not fused.is_cuda
+    lib = _lib.load() if host else _lib.require_gpu()
     fused = fused.float().contiguous()
     B, E = fused.shape
     nbits = hash_fc.out_features
@@ -50,7 +52,12 @@ def hash_tail(fused, hash_fc, bn, want=("codes",)):
     bb = bn.bias.detach().float().contiguous() if use_bn else None
     bm = bn.running_mean.detach().float().contiguous() if use_bn else None
     bv = bn.running_var.detach().float().contiguous() if use_bn else None
-    if B:
+    if B and host:
+        rc = lib.wv_hash_tail_cpu(_lib.ptr(fused), B, E, _lib.ptr(w), _lib.ptr(hb), _lib.ptr(bw), _lib.ptr(bb), _lib.ptr(bm),
+                                  _lib.ptr(bv), float(bn.eps) if use_bn else 0.0, nbits, _lib.ptr(logits), _lib.ptr(codes),
+                                  _lib.ptr(packed))
+        _lib.check(rc, "wv_hash_tail_cpu")
+    elif B:
         with torch.cuda.device(dev):
             rc = lib.wv_hash_tail(_lib.ptr(fused), B, E, _lib.ptr(w), _lib.ptr(hb), _lib.ptr(bw), _lib.ptr(bb),
                                   _lib.ptr(bm), _lib.ptr(bv), float(bn.eps) if use_bn else 0.0, nbits,
@@ -109,8 +116,9 @@ class _WaveletHashingBase(nn.Module):
         return tf.apply_batch(x).permute(2, 0, 1, 3, 4)
 
     def _tail(self, fused_embedding):
-        if not self.training and fused_embedding.is_cuda and not torch.is_grad_enabled():
-            return hash_tail(fused_embedding, self.hash_fc, self.bn, want=("codes",))["codes"]
+        host = not fused_embedding.is_cuda and getattr(self, "host_twin", False)      # explicit: model.host_twin = True
+        if not self.training and (fused_embedding.is_cuda or host) and not torch.is_grad_enabled():
+            return hash_tail(fused_embedding, self.hash_fc, self.bn, want=("codes",), host_twin=host)["codes"]
         logits = self.bn(self.hash_fc(fused_embedding))
         return self._train_output(logits) if self.training else torch.sign(logits)
 

@@ -44,7 +44,8 @@ extern "C" {
 #define WV_LAYOUT_NHWC 1 /* [B][H][W][C]  (PIL / numpy, what np.array(img) yields) */
 
 const char *wv_last_error(void);
-/* 4 = this header.  History: 4 added the host twins of the ranking side (wv_pack_bits_cpu ... wv_hit_prefix_cpu); 2 added wv_head_params.q_proj, the host twins, wv_swt2d_forward_ex, the two-step shard entry
+/* 5 = this header.  History: 5 added WV_METRIC_L2_SQUARED and the host twins wv_knn_float_cpu, wv_band_attn_pool_cpu,
+ * wv_hash_tail_cpu; 4 added the host twins of the ranking side (wv_pack_bits_cpu ... wv_hit_prefix_cpu); 2 added wv_head_params.q_proj, the host twins, wv_swt2d_forward_ex, the two-step shard entry
  * points and wv_map_at_k_ld; 3 added wv_head_params.prepared / wv_band_attn_prepare (one-launch head front), the ranking + AP
  * entry points (wv_hamming_map_at_k, wv_rank_labels_prepare), wv_hamming_shard_prefix / wv_topk_merge_cum_need and the
  * relevance-string pair of the sharded mAP (wv_hamming_shard_relbits, wv_merge_relbits_map).  A struct gaining a field bumps it. */
@@ -323,6 +324,10 @@ int wv_hit_prefix(const int32_t *idx, int Q, int k, const uint64_t *qlab, const 
 size_t wv_knn_float_workspace_bytes(int Q, int64_t N, int D, int k);
 int wv_knn_float(const float *q, const float *db, int Q, int64_t N, int D, int metric, int k,
                  int32_t *idx, float *val, void *workspace, size_t workspace_bytes, void *stream);
+/* Host twin (HOST pointers, no stream, no workspace; csrc/host_knn.cpp): the same indices and values bit for bit --
+ * v_mfma_f32_32x32x2_f32 is an fmaf chain (k = 0 before k = 1; tools/mfma_order_test.hip), the twin walks k in the order
+ * the kernel feeds it, forms the squared norms in the kernel's lane / butterfly order and ranks on the same keys. */
+int wv_knn_float_cpu(const float *q, const float *db, int Q, int64_t N, int D, int metric, int k, int32_t *idx, float *val);
 
 /* ------------------------------------------------------------------------------------------
  * Band-attention pooling head + hashing tail (eval mode).
@@ -382,6 +387,16 @@ int wv_hash_tail(const float *fused, int B, int E, const float *hash_w, const fl
                  const float *bn_w, const float *bn_b, const float *bn_mean, const float *bn_var,
                  float bn_eps, int nbits, float *logits_out, float *codes_out,
                  uint64_t *packed_out, void *stream);
+
+/* Host twins of the two entry points above (HOST pointers everywhere, incl. the members of wv_head_params; q_proj and
+ * prepared are ignored; no stream, no workspace; csrc/host_head.cpp) for a model whose tensors live on the host.  fp32 with
+ * a machine-independent summation order (eight interleaved fmaf chains, one fixed tree); they agree with the kernels to
+ * fp32 rounding (both are held to the reference-made golden vectors with the same tolerance), the codes wherever the
+ * logit is not within that of zero. */
+int wv_band_attn_pool_cpu(const wv_head_params *p, const float *feats, int B, float *out);
+int wv_hash_tail_cpu(const float *fused, int B, int E, const float *hash_w, const float *hash_b, const float *bn_w,
+                     const float *bn_b, const float *bn_mean, const float *bn_var, float bn_eps, int nbits,
+                     float *logits_out, float *codes_out, uint64_t *packed_out);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,7 @@ static uint32_t rnd() { rng_state = rng_state * 1664525u + 1013904223u; return r
 
 int main()
 {
-    if (wv_abi_version() != 4) { fprintf(stderr, "abi version %d\n", wv_abi_version()); return 1; }
+    if (wv_abi_version() != 5) { fprintf(stderr, "abi version %d\n", wv_abi_version()); return 1; }
     hipStream_t st;
     HIPOK(hipStreamCreate(&st));
 

@@ -20,7 +20,7 @@
 
 int main(void)
 {
-    CHECK(wv_abi_version() == 4);
+    CHECK(wv_abi_version() == 5);
     /* ---- SWT twin: constant uint8 image 200 -> cA = 2 * 200/255, details exactly 0 */
     enum { H = 8, W = 8 };
     uint8_t img[3 * H * W];
@@ -63,8 +63,25 @@ int main(void)
     CHECK(wv_hit_prefix_cpu(&lists[0][0], 2, 3, qlab, dblab, 1, &hits[0][0]) == WV_OK);
     CHECK(hits[0][0] == 1 && hits[0][1] == 1 && hits[0][2] == 2 && hits[1][2] == 0);
     CHECK(wv_bit_counts_cpu(dbp, 4, 8, counts) == WV_OK && counts[0] == 3 && counts[7] == 1);
+    /* ---- real-valued k-NN twin on the same +-1 rows: inner products 8 - 2 * hamming, squared L2 = 4 * hamming; ties (none
+     * here) by ascending row */
+    int32_t ki[2][3];
+    float kv[2][3];
+    CHECK(wv_knn_float_cpu(&q[0][0], &db[0][0], 2, 4, 8, WV_METRIC_IP, 3, &ki[0][0], &kv[0][0]) == WV_OK);
+    CHECK(ki[0][0] == 0 && ki[0][1] == 3 && ki[0][2] == 1 && kv[0][0] == 8.0f && kv[0][1] == 6.0f && kv[0][2] == 0.0f);
+    CHECK(wv_knn_float_cpu(&q[0][0], &db[0][0], 2, 4, 8, WV_METRIC_L2_SQUARED, 3, &ki[0][0], &kv[0][0]) == WV_OK);
+    CHECK(ki[1][0] == 2 && ki[1][1] == 1 && ki[1][2] == 0 && kv[1][0] == 4.0f && kv[1][1] == 20.0f && kv[1][2] == 28.0f);
+    CHECK(wv_knn_float_cpu(&q[0][0], &db[0][0], 2, 4, 8, WV_METRIC_L2, 1, &ki[0][0], &kv[0][0]) == WV_OK && kv[0][1] == 2.0f);
+    /* ---- hashing tail twin: identity-like hash matrix on the first database row pair, no BatchNorm */
+    {
+        float hw[2][8] = {{1, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, -1}}, logits[2][2], codes[2][2];
+        uint64_t pk[2];
+        CHECK(wv_hash_tail_cpu(&db[0][0], 2, 8, &hw[0][0], NULL, NULL, NULL, NULL, NULL, 0.0f, 2, &logits[0][0], &codes[0][0], pk) == WV_OK);
+        CHECK(logits[0][0] == 1.0f && logits[0][1] == -1.0f && logits[1][1] == 1.0f && codes[1][1] == 1.0f && pk[0] == 1 && pk[1] == 3);
+    }
     /* argument validation answers with a code and a message, never a crash */
     CHECK(wv_hamming_topk_cpu(qp, dbp, &idx[0][0], NULL, 2, 4, 8, 5, 0) == WV_EINVAL && strstr(wv_last_error(), "k=5"));
+    CHECK(wv_knn_float_cpu(&q[0][0], &db[0][0], 2, 4, 6, WV_METRIC_IP, 3, &ki[0][0], &kv[0][0]) == WV_EINVAL);
     printf("host_smoke ok\n");
     return 0;
 }

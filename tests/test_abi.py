@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} declared in include/wvhash.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == syms
-    assert lib.wv_abi_version() == 4
+    assert lib.wv_abi_version() == 5
 
 
 def test_release_library_never_reads_the_environment():

@@ -132,3 +132,20 @@ def test_query_chunks_of_a_long_database(diag):
     q, r = torch.randn(Q, D, generator=g).cuda(), torch.randn(N, D, generator=g).cuda()
     (v1, i1), (v0, i0) = _both(diag, r, q, k, L2)
     assert torch.equal(i1, i0) and torch.equal(v1.view(torch.int32), v0.view(torch.int32))
+
+
+@pytest.mark.parametrize("D", [4, 64, 100, 384])
+def test_host_twin_equals_the_kernels_bit_for_bit(D):
+    """wv_knn_float_cpu (csrc/host_knn.cpp) on random real-valued embeddings: v_mfma_f32_32x32x2_f32 is an fmaf chain, the
+    twin walks k in the order the kernel feeds it and forms the norms in the kernel's lane / butterfly order -- so indices
+    AND values are equal bit for bit, for every metric (ties or not)."""
+    from wvhash.engine.get_knn import knn_float_host
+    g = torch.Generator().manual_seed(D)
+    Q, N, k = 33, 3000, 200
+    q, r = torch.randn(Q, D, generator=g), torch.randn(N, D, generator=g)
+    r[5] = q[3]                                                     # an exact match: squared distance 0 (or the clamp)
+    for metric in (IP, L2, _lib.WV_METRIC_L2_SQUARED):
+        vg, ig = knn_float(r.cuda(), q.cuda(), k, metric)
+        vh, ih = knn_float_host(r, q, k, metric)
+        assert torch.equal(ig.cpu(), ih), metric
+        assert torch.equal(vg.cpu().view(torch.int32), vh.view(torch.int32)), metric

@@ -93,8 +93,8 @@ def test_calculator_on_cpu_runs_the_c0_shape_without_a_gpu():
 def test_cpu_calculator_refuses_what_it_does_not_cover():
     from wvhash import _lib
     calc = CustomCalculator(k=5, device="cpu", distance_metric="cosine", with_faiss=False)
-    x = torch.randn(6, 16)
-    with pytest.raises(_lib.WvhashUnavailable, match="device='cpu' covers"):
+    x = torch.randn(6, 18)
+    with pytest.raises(_lib.WvhashUnavailable, match="multiple of 4"):
         calc._host_knn(x, x[:2], 3, False)
     with pytest.raises(ValueError, match="exactly"):
         calc.calculate_maphashing(torch.zeros(2, 16), torch.ones(2, 3), torch.ones(4, 16), torch.ones(4, 3), 2)
