@@ -134,7 +134,6 @@ extern "C" int wv_knn_float_cpu(const float *q, const float *db, int Q, int64_t 
                metric);
     HK_REQUIRE(k >= 1 && k <= N, "knn_float_cpu: k=%d must be in [1, N=%lld] (torch.topk raises too)", k, (long long)N);
     HK_REQUIRE(N <= (1ll << 26), "knn_float_cpu: N=%lld above the supported 2^26 rows", (long long)N);
-    HK_REQUIRE((D % 4) == 0, "knn_float_cpu: embedding dimension %d must be a multiple of 4", D);
     if (Q == 0) return WV_OK;
     const bool l2 = metric != WV_METRIC_IP, desc = !l2;
     const std::vector<int> ord = accumulation_order(D);

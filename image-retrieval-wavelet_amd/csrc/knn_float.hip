@@ -58,7 +58,17 @@ __global__ __launch_bounds__(256) void k_pack_fragments(const float *__restrict_
     const int64_t row = (bc / nchunk) * 32 + (lane & 31);
     const int k = 8 * c + 4 * (lane >> 5);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < rows && k < D) v = *reinterpret_cast<const float4 *>(x + row * D + k);   // D % 4 == 0
+    if (row < rows && k < D) {
+        const float *src = x + row * D + k;
+        if ((D & 3) == 0) {              // rows are 16-byte aligned: one load
+            v = *reinterpret_cast<const float4 *>(src);
+        } else {                         // any embedding dimension: element by element, zeros beyond D
+            v.x = src[0];
+            if (k + 1 < D) v.y = src[1];
+            if (k + 2 < D) v.z = src[2];
+            if (k + 3 < D) v.w = src[3];
+        }
+    }
     out[o] = v;
 }
 
@@ -789,7 +799,6 @@ extern "C" int wv_knn_float(const float *q, const float *db, int Q, int64_t N, i
     WV_REQUIRE(k >= 1 && k <= N, "knn_float: k=%d must be in [1, N=%lld] (torch.topk raises too)", k,
                (long long)N);
     WV_REQUIRE(N <= (1ll << 26), "knn_float: N=%lld above the supported 2^26 rows", (long long)N);
-    WV_REQUIRE((D % 4) == 0, "knn_float: embedding dimension %d must be a multiple of 4", D);
     const size_t need = wv_knn_float_workspace_bytes(Q, N, D, k);
     if (!workspace || workspace_bytes < need)
         WV_FAIL(WV_ENOMEM, "knn_float: workspace %zu < %zu bytes", workspace_bytes, need);

@@ -391,8 +391,6 @@ class CustomCalculator(object):
         if self.distance_metric == "hamming" and nbits <= 128 and _is_pm1(reference) and _is_pm1(query):
             idx, dist = HH.hamming_topk(HH.pack_codes(query, check=False), HH.pack_codes(reference, check=False), nbits, num_k)
             return idx[:, first:].long(), (float(nbits) - 2.0 * dist.float())[:, first:]
-        if nbits % 4:
-            raise _lib.WvhashUnavailable(f"float k-NN needs an embedding dimension that is a multiple of 4 (got {nbits})")
         if self.distance_metric in ("hamming", "cosine"):
             metric = _lib.WV_METRIC_IP
         else:                                   # faiss IndexFlatL2 returns squared distances, torch.cdist the root

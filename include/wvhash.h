@@ -316,7 +316,8 @@ int wv_hit_prefix(const int32_t *idx, int Q, int k, const uint64_t *qlab, const 
  *   metric 2: the same neighbours with faiss IndexFlatL2's SQUARED distances (get_knn.py:38-39,55)
  * L2 rows are ranked on the squared distance |q|^2 + |r|^2 - 2 q.r (clamped at 0) -- what faiss ranks on, and
  * torch.cdist's order up to the ties the rounding of the root creates; metric 1 takes the root of the k results.
- * Ties are broken by ascending database index.  idx int32 [Q][k], val float32 [Q][k].  D % 4 == 0, N <= 2^26.
+ * Ties are broken by ascending database index.  idx int32 [Q][k], val float32 [Q][k].  Any D >= 1 (rows 16-byte aligned when D % 4 == 0), N <= 2^26,
+ * q and db 16-byte aligned.
  * ------------------------------------------------------------------------------------------ */
 #define WV_METRIC_IP 0
 #define WV_METRIC_L2 1

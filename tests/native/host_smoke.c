@@ -81,7 +81,7 @@ int main(void)
     }
     /* argument validation answers with a code and a message, never a crash */
     CHECK(wv_hamming_topk_cpu(qp, dbp, &idx[0][0], NULL, 2, 4, 8, 5, 0) == WV_EINVAL && strstr(wv_last_error(), "k=5"));
-    CHECK(wv_knn_float_cpu(&q[0][0], &db[0][0], 2, 4, 6, WV_METRIC_IP, 3, &ki[0][0], &kv[0][0]) == WV_EINVAL);
+    CHECK(wv_knn_float_cpu(&q[0][0], &db[0][0], 2, 4, 8, WV_METRIC_IP, 5, &ki[0][0], &kv[0][0]) == WV_EINVAL);   /* k > N */
     printf("host_smoke ok\n");
     return 0;
 }

@@ -87,8 +87,9 @@ def test_error_codes_on_the_gpu():
     idx = torch.zeros((2, 4), dtype=torch.int32, device="cuda")
     assert lib.wv_hamming_topk(_lib.ptr(q), _lib.ptr(q), _lib.ptr(idx), None, 2, 2, 64, 4, 0, _lib.ptr(q), 8, sp()) == -22
     assert lib.wv_map_at_k(_lib.ptr(idx), 2, 0, _lib.ptr(q), _lib.ptr(q), 1, _lib.ptr(idx), None, sp()) == -22
-    assert lib.wv_knn_float(_lib.ptr(q), _lib.ptr(q), 2, 2, 6, 0, 1, _lib.ptr(idx), _lib.ptr(idx), _lib.ptr(q), 8, sp()) == -22
-    assert b"multiple of 4" in lib.wv_last_error()
+    assert lib.wv_knn_float(_lib.ptr(q), _lib.ptr(q), 2, 2, 6, 7, 1, _lib.ptr(idx), _lib.ptr(idx), _lib.ptr(q), 8, sp()) == -22
+    assert b"metric" in lib.wv_last_error()
+    assert lib.wv_knn_float(_lib.ptr(q), _lib.ptr(q), 2, 2, 6, 0, 1, _lib.ptr(idx), _lib.ptr(idx), _lib.ptr(q), 8, sp()) == -12   # workspace
 
 
 def test_native_consumer_without_torch_or_python():

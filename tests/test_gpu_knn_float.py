@@ -89,7 +89,7 @@ def test_row_topk_against_the_stable_oracle(metric, name):
     np.testing.assert_allclose(v.cpu().numpy(), sd.numpy(), rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("D", [4, 12, 16, 20, 36, 52, 100, 384])
+@pytest.mark.parametrize("D", [1, 3, 4, 7, 12, 16, 20, 36, 52, 70, 100, 384])
 def test_scores_are_exact_for_every_tail_of_the_k_loop(D):
     """k_scores walks k in chunks of 16 with a two-stage register pipeline; the last chunk may hold 4, 8 or 12 values.
     Integer-valued embeddings: every product and partial sum is exact in fp32, whatever the summation order, so the
@@ -134,7 +134,7 @@ def test_query_chunks_of_a_long_database(diag):
     assert torch.equal(i1, i0) and torch.equal(v1.view(torch.int32), v0.view(torch.int32))
 
 
-@pytest.mark.parametrize("D", [4, 64, 100, 384])
+@pytest.mark.parametrize("D", [3, 4, 64, 70, 100, 384])
 def test_host_twin_equals_the_kernels_bit_for_bit(D):
     """wv_knn_float_cpu (csrc/host_knn.cpp) on random real-valued embeddings: v_mfma_f32_32x32x2_f32 is an fmaf chain, the
     twin walks k in the order the kernel feeds it and forms the norms in the kernel's lane / butterfly order -- so indices

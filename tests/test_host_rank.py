@@ -94,7 +94,7 @@ def test_cpu_calculator_refuses_what_it_does_not_cover():
     from wvhash import _lib
     calc = CustomCalculator(k=5, device="cpu", distance_metric="cosine", with_faiss=False)
     x = torch.randn(6, 18)
-    with pytest.raises(_lib.WvhashUnavailable, match="multiple of 4"):
-        calc._host_knn(x, x[:2], 3, False)
+    idx, _ = calc._host_knn(x, x[:2], 3, False)                  # real-valued embeddings: the float twin (any dimension)
+    assert idx[:, 0].tolist() == [0, 1]
     with pytest.raises(ValueError, match="exactly"):
         calc.calculate_maphashing(torch.zeros(2, 16), torch.ones(2, 3), torch.ones(4, 16), torch.ones(4, 3), 2)
