@@ -583,8 +583,66 @@ __device__ __forceinline__ uint32_t tk_scan_bins(const uint32_t *cnt, uint32_t *
     return e0;
 }
 
+enum { TK_BSTAR = 0, TK_BEFORE = 1, TK_COUNT = 2, TK_NAN_SEEN = 3, TK_GMAX = 4, TK_BLO = 5, TK_FOUND = 6 };   // sel[]
+
+// Value-bin histogram of the whole row (cursor[] zeroed by the caller), exclusive prefix in place, the bin b* where the
+// running count reaches k -> true when the list fits (b* found, at most cap items up to b*, no bin up to b* beyond
+// kTkGroupMax).  If the bins of the sampled range are too coarse where it matters -- outliers stretched [lo, hi] -- the
+// histogram still says where the first k items lie, and the caller makes ONE second attempt that spreads [the bin holding
+// item k / 16, b*] of the first over all 4096 bins (SECOND: items far above pile up in the last bin and are not counted; if
+// item k lands there after all, the row goes to the radix kernel).  Any range is a correct binning.
+template <bool SECOND>
+__device__ __forceinline__ bool tk_histogram(const float *__restrict__ Srow, int64_t N, int k, int cap, bool desc, float lo,
+                                             float scale, uint32_t *cursor, uint32_t *wpart, uint32_t *sel)
+{
+    constexpr int UNR = kTkUnroll;
+    const int tid = threadIdx.x, lane = lane_id();
+    bool nan_seen = false;
+    for (int64_t i0 = tid; i0 < N; i0 += (int64_t)kTkThreads * UNR) {
+        float v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t i = i0 + (int64_t)u * kTkThreads;
+            v[u] = Srow[min(i, N - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (i0 + (int64_t)u * kTkThreads >= N) break;
+            const float w = tk_order_value(v[u], desc);
+            nan_seen |= w != w;
+            const int b = tk_bin(w, lo, scale);
+            if (!SECOND || b < kTkBins - 1)
+                __hip_atomic_fetch_add(&cursor[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    if (nan_seen) sel[TK_NAN_SEEN] = 1;
+    __syncthreads();
+    uint4 c;
+    const uint32_t e0 = tk_scan_bins(cursor, wpart, c), e1 = e0 + c.x, e2 = e1 + c.y, e3 = e2 + c.z;
+    *reinterpret_cast<uint4 *>(cursor + 4 * tid) = make_uint4(e0, e1, e2, e3);
+    const uint32_t kk = (uint32_t)k, klo = max(1u, min(kk / 16u, 256u));
+    const uint32_t e[4] = {e0, e1, e2, e3}, cc[4] = {c.x, c.y, c.z, c.w};
+    uint32_t g = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        if (e[b] < kk && kk <= e[b] + cc[b]) {
+            sel[TK_BSTAR] = 4 * tid + b; sel[TK_BEFORE] = e[b]; sel[TK_COUNT] = cc[b]; sel[TK_FOUND] = 1;
+        }
+        if (!SECOND && e[b] < klo && klo <= e[b] + cc[b]) sel[TK_BLO] = 4 * tid + b;
+        g = max(g, e[b] < kk ? cc[b] : 0u);
+    }
+    const uint32_t gw = (uint32_t)__reduce_max_sync(~0ull, g);
+    if (lane == 0) __hip_atomic_fetch_max(&sel[TK_GMAX], gw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    return sel[TK_FOUND] && sel[TK_BEFORE] + sel[TK_COUNT] <= (uint32_t)cap && sel[TK_GMAX] <= (uint32_t)kTkGroupMax;
+}
+
+// Occupancy: two workgroups of 1024 threads per CU = 8 waves per SIMD need <= 64 VGPRs AND <= 80 SGPRs (the 800-entry scalar
+// file holds 16 more per wave than the kernel asks for: at 96 a SIMD takes 7 waves, i.e. ONE workgroup per CU, and every phase
+// of this latency-bound kernel ran 1.5 x longer -- measured when the second binning attempt pushed the count from 80 to 96).
+// The bound makes the compiler keep to 78 (two scalars spilled to a VGPR's lanes).  JMAX = 16 needs 147 KB of LDS: one per CU anyway.
 template <int JMAX>
-__global__ __launch_bounds__(kTkThreads) void k_row_topk(const float *__restrict__ S, int64_t N, int k, int cap,
+__global__ __launch_bounds__(kTkThreads, (JMAX <= 8 ? 8 : 4)) void k_row_topk(const float *__restrict__ S, int64_t N, int k, int cap,
                                                          int descending, int32_t *__restrict__ idx_out,
                                                          float *__restrict__ val_out, uint8_t *__restrict__ todo,
                                                          int force_radix, int sqrt_out)
@@ -595,7 +653,6 @@ __global__ __launch_bounds__(kTkThreads) void k_row_topk(const float *__restrict
     float *fpart = reinterpret_cast<float *>(wpart + 32);       // [32]   wave minima, wave maxima
     uint32_t *sel = reinterpret_cast<uint32_t *>(fpart + 32);   // [8]    see the enum
     uint64_t *A = reinterpret_cast<uint64_t *>(sel + 8);        // [cap]  (key << 32 | index)
-    enum { BSTAR = 0, BEFORE = 1, COUNT = 2, NAN_SEEN = 3, GMAX = 4 };
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     const int64_t row = blockIdx.x;
     const float *Srow = S + row * N;
@@ -643,51 +700,36 @@ __global__ __launch_bounds__(kTkThreads) void k_row_topk(const float *__restrict
     if (!(scale > 0.f)) scale = 0.f;                 // constant sample, infinite range, NaN: everything in one bin
     TK_STOP(1);
 
-    // pass 1: value-bin histogram of the whole row
+    // pass 1: value-bin histogram and the bin b* of the k-th item; one second attempt with a range taken from the first
+    // histogram when outliers made the sampled range too coarse (tk_histogram)
     constexpr int UNR = kTkUnroll;
-    bool nan_seen = false;
-    for (int64_t i0 = tid; i0 < N; i0 += (int64_t)kTkThreads * UNR) {
-        float v[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int64_t i = i0 + (int64_t)u * kTkThreads;
-            v[u] = Srow[min(i, N - 1)];
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            if (i0 + (int64_t)u * kTkThreads >= N) break;
-            const float w = tk_order_value(v[u], desc);
-            nan_seen |= w != w;
-            __hip_atomic_fetch_add(&cursor[tk_bin(w, lo, scale)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    }
-    if (nan_seen) sel[NAN_SEEN] = 1;
-    __syncthreads();
+    bool fits = tk_histogram<false>(Srow, N, k, cap, desc, lo, scale, cursor, wpart, sel);
     TK_STOP(2);
-
-    // exclusive prefix over the bins; the bin where the running count reaches k
-    {
-        uint4 c;
-        const uint32_t e0 = tk_scan_bins(cursor, wpart, c), e1 = e0 + c.x, e2 = e1 + c.y, e3 = e2 + c.z;
-        *reinterpret_cast<uint4 *>(cursor + 4 * tid) = make_uint4(e0, e1, e2, e3);
-        const uint32_t kk = (uint32_t)k;
-        const uint32_t e[4] = {e0, e1, e2, e3}, cc[4] = {c.x, c.y, c.z, c.w};
-        uint32_t g = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            if (e[b] < kk && kk <= e[b] + cc[b]) { sel[BSTAR] = 4 * tid + b; sel[BEFORE] = e[b]; sel[COUNT] = cc[b]; }
-            g = max(g, e[b] < kk ? cc[b] : 0u);
-        }
-        const uint32_t gw = (uint32_t)__reduce_max_sync(~0ull, g);
-        if (lane == 0) __hip_atomic_fetch_max(&sel[GMAX], gw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    __syncthreads();
-    const int bstar = (int)sel[BSTAR];
-    const uint32_t n_tot = sel[BEFORE] + sel[COUNT];
-    if (n_tot > (uint32_t)cap || sel[GMAX] > (uint32_t)kTkGroupMax || sel[NAN_SEEN] || force_radix) {
+    if (sel[TK_NAN_SEEN] || force_radix || (!fits && !(scale > 0.f))) {
         if (tid == 0) todo[row] = 1;
         return;
     }
+    if (!fits) {
+        // second attempt: [lower edge of bin b_lo, upper edge of bin b*] in the order value's space
+        const float inv = 1.f / scale;
+        const float nlo = fmaf((float)((int)sel[TK_BLO] - 64), inv, lo), nhi = fmaf((float)((int)sel[TK_BSTAR] + 1 - 64), inv, lo);
+        __syncthreads();                                  // everybody has read sel[]
+        lo = nlo;
+        scale = (float)(kTkBins - 128) / (nhi - nlo);
+        if (!(scale > 0.f) || !(scale < __builtin_inff())) {
+            if (tid == 0) todo[row] = 1;
+            return;
+        }
+        *reinterpret_cast<uint4 *>(cursor + 4 * tid) = make_uint4(0, 0, 0, 0);
+        if (tid < 8) sel[tid] = 0;
+        __syncthreads();
+        if (!tk_histogram<true>(Srow, N, k, cap, desc, lo, scale, cursor, wpart, sel)) {
+            if (tid == 0) todo[row] = 1;
+            return;
+        }
+    }
+    const int bstar = (int)sel[TK_BSTAR];
+    const uint32_t n_tot = sel[TK_BEFORE] + sel[TK_COUNT];
     if (tid == 0) todo[row] = 0;
     TK_STOP(3);
 

@@ -30,6 +30,8 @@ def case(Q, N, D, k, metric, name):
     g = torch.Generator().manual_seed(7)
     q = torch.randn(Q, D, generator=g).cuda()
     r = torch.randn(N, D, generator=g).cuda()
+    if "outliers" in name:                        # 1 % of the database rows 100 x longer: they stretch every row's score range
+        r[torch.randperm(N, generator=g)[: N // 100].cuda()] *= 100.0
     us = t_us(lambda: knn_float(r, q, k, metric))
     fl = 2.0 * Q * N * D
     print(f"{name:34s} Q={Q:6d} N={N:6d} D={D:4d} k={k:6d}: {us:9.1f} us  {fl / us / 1e6:7.1f} TFLOP/s (scores only counted)",
@@ -47,6 +49,8 @@ if __name__ == "__main__":
         (5823, 5717, 384, 5717, _lib.WV_METRIC_IP, "c0 IP k=N"),
         (5000, 117224, 384, 5000, _lib.WV_METRIC_L2, "c3 L2 k=5000"),
         (2048, 25000, 64, 5000, _lib.WV_METRIC_IP, "c1 IP k=5000 D=64 (tanh codes)"),
+        (2048, 25000, 384, 5000, _lib.WV_METRIC_IP, "c1 IP k=5000 outliers"),
+        (2048, 25000, 384, 5000, _lib.WV_METRIC_L2, "c1 L2 k=5000 outliers"),
     ]
     exact = any(only == c[5] for c in cases)
     for c in cases:
