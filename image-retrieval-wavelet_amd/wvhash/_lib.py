@@ -19,6 +19,7 @@ DIAG_LIB_PATH = os.path.join(_HERE, "_lib", "libwvhash_diag.so")
 WV_DT_U8, WV_DT_F32, WV_DT_BF16 = 0, 1, 2
 WV_LAYOUT_NCHW, WV_LAYOUT_NHWC = 0, 1
 WV_METRIC_IP, WV_METRIC_L2, WV_METRIC_L2_SQUARED = 0, 1, 2
+ABI_VERSION = 5        # what include/wvhash.h documents; load() refuses a library that reports another one
 WV_BANDS_INNER, WV_BANDS_OUTER = 0, 1
 
 
@@ -128,6 +129,11 @@ def _open(path):
         lib = ctypes.CDLL(path)
     except OSError as e:  # pragma: no cover
         raise WvhashUnavailable(f"cannot load {path}: {e}") from e
+    lib.wv_abi_version.restype = ctypes.c_int
+    have = lib.wv_abi_version()
+    if have != ABI_VERSION:
+        raise WvhashUnavailable(f"{path} reports ABI {have}, this package binds ABI {ABI_VERSION}: rebuild it "
+                                "(`python -c 'import __graft_entry__ as g; g.build()'`)")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res

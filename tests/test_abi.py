@@ -29,7 +29,9 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} declared in include/wvhash.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == syms
-    assert lib.wv_abi_version() == 5
+    assert lib.wv_abi_version() == _lib.ABI_VERSION == 5
+    import __graft_entry__                               # build() checks the same constant
+    assert "_lib.ABI_VERSION" in open(__graft_entry__.__file__).read()
 
 
 def test_release_library_never_reads_the_environment():
