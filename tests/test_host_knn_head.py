@@ -1,14 +1,13 @@
 """Host twins of the real-valued k-NN, the attention-pooling head and the hashing tail ("_cpu twins of
 each"; csrc/host_knn.cpp, csrc/host_head.cpp) on a box without a GPU: against the stable oracle, the reference-made golden
 vectors of the head (tests/golden/head_golden.npz, same tolerance as the kernels: 5e-5) and stock torch."""
-import ctypes
 import os
 
 import numpy as np
 import pytest
 import torch
 
-from oracle import head_torch, ranking
+from oracle import ranking
 from wvhash import _lib
 from wvhash.engine import CustomCalculator
 from wvhash.engine.get_knn import knn_float_host
