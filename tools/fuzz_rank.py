@@ -6,7 +6,7 @@ import numpy as np, torch
 from oracle import ranking
 from wvhash import synth
 from wvhash.engine import hamming as H, get_knn
-rng = np.random.default_rng(7)
+rng = np.random.default_rng(int(__import__("os").environ.get("WV_FUZZ_SEED", "7")))
 bad = n = 0
 for it in range(60):                                   # Hamming top-k: random sizes
     Q = int(rng.integers(1, 40)); N = int(rng.integers(1, 9000)); nbits = int(rng.choice([16, 32, 48, 64, 128]))

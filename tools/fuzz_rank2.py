@@ -11,7 +11,7 @@ from oracle import ranking
 from wvhash import synth
 from wvhash.engine import hamming as H
 
-rng = np.random.default_rng(11)
+rng = np.random.default_rng(int(os.environ.get("WV_FUZZ_SEED", "11")))
 bad = n = 0
 for it in range(150):
     nbits = int(rng.choice([8, 16, 31, 32, 48, 64, 65, 100, 128]))

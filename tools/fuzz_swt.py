@@ -4,7 +4,7 @@ sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "image-retrieval
 import numpy as np, torch
 from oracle import swt_np
 from wvhash.transforms import swt2d
-rng = np.random.default_rng(2024)
+rng = np.random.default_rng(int(__import__("os").environ.get("WV_FUZZ_SEED", "2024")))
 bad = 0; n = 0
 wl_levels = [("haar", 1), ("haar", 2), ("haar", 3), ("db2", 1), ("db2", 2), ("db2", 3), ("db4", 1), ("bior4.4", 1), ("db4", 2), ("bior4.4", 2)]
 for it in range(220):
