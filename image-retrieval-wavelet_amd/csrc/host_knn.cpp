@@ -173,3 +173,27 @@ extern "C" int wv_knn_float_cpu(const float *q, const float *db, int Q, int64_t 
     }
     return WV_OK;
 }
+
+extern "C" int wv_rank_scores_cpu(const float *S, int Q, int64_t N, int k, int flags, int32_t *idx, float *val)
+{
+    HK_REQUIRE(S && idx && val, "rank_scores_cpu: null buffer");
+    HK_REQUIRE(Q >= 0 && N >= 1, "rank_scores_cpu: bad shape Q=%d N=%lld", Q, (long long)N);
+    HK_REQUIRE(k >= 1 && k <= N, "rank_scores_cpu: k=%d must be in [1, N=%lld]", k, (long long)N);
+    HK_REQUIRE(N <= (1ll << 26), "rank_scores_cpu: N=%lld above the supported 2^26 columns", (long long)N);
+    HK_REQUIRE((flags & ~(WV_RANK_DESCENDING | WV_RANK_SQRT)) == 0, "rank_scores_cpu: flags %d", flags);
+    const bool desc = (flags & WV_RANK_DESCENDING) != 0, root = (flags & WV_RANK_SQRT) != 0;
+    std::vector<uint64_t> keyed((size_t)N);
+    for (int qi = 0; qi < Q; ++qi) {
+        const float *row = S + (size_t)qi * N;
+        for (int64_t n = 0; n < N; ++n) keyed[(size_t)n] = ((uint64_t)float_to_key(row[n], desc) << 32) | (uint32_t)n;
+        if ((int64_t)k < N) std::nth_element(keyed.begin(), keyed.begin() + k, keyed.end());
+        std::sort(keyed.begin(), keyed.begin() + k);
+        for (int j = 0; j < k; ++j) {
+            const uint64_t e = keyed[(size_t)j];
+            const float v = key_to_float((uint32_t)(e >> 32), desc);
+            idx[(size_t)qi * k + j] = (int32_t)(uint32_t)e;
+            val[(size_t)qi * k + j] = root ? sqrtf(v) : v;
+        }
+    }
+    return WV_OK;
+}

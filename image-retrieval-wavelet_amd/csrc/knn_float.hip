@@ -807,6 +807,42 @@ static int launch_row_topk(const float *S, int64_t N, int k, int cap, int descen
     return WV_OK;
 }
 
+// The ranking stage: the k best of every row of S [qc][N] in ascending (key, column) order.  Rows the one-kernel ranking takes
+// never reach the radix kernel (its workgroups return at once on todo[row] == 0).
+static int rank_rows(const float *S, int qc, int64_t N, int k, int descending, int sqrt_out, int32_t *idx, float *val,
+                     uint8_t *todo_buf, uint2 *bufA, uint2 *bufB, hipStream_t st)
+{
+    const int C = (int)ceil_div(N, kRadixThreads);
+    const uint32_t c_magic = C <= 1 ? 0u : (uint32_t)(((1ull << 32) + C - 1) / C);   // exact for pos < 2^32 / C
+    const uint8_t *todo = nullptr;
+    if (k + kTkSlack <= kTkCapMax && !::wv::tune("WV_KNN_RADIX_ONLY")) {
+        const int cap = (int)std::min<int64_t>(kTkCapMax, align_up(k + kTkSlack, kTkThreads));
+        int force = ::wv::tune("WV_KNN_FORCE_TODO") ? 1 : 0;   // diagnostic build: every row takes both kernels' hand-over
+        if (const char *stop = ::wv::tune("WV_TK_STOP")) force |= atoi(stop) << 8;
+        const int J = cap / kTkThreads;
+        int rc;
+        if (J <= 2) rc = launch_row_topk<2>(S, N, k, cap, descending, idx, val, todo_buf, force, sqrt_out, qc, st);
+        else if (J <= 4) rc = launch_row_topk<4>(S, N, k, cap, descending, idx, val, todo_buf, force, sqrt_out, qc, st);
+        else if (J <= 8) rc = launch_row_topk<8>(S, N, k, cap, descending, idx, val, todo_buf, force, sqrt_out, qc, st);
+        else rc = launch_row_topk<16>(S, N, k, cap, descending, idx, val, todo_buf, force, sqrt_out, qc, st);
+        if (rc != WV_OK) return rc;
+        todo = todo_buf;
+    }
+    const int select_first = (int64_t)k * 2 <= N && !::wv::tune("WV_KNN_FULLSORT");
+    const int Ck = (int)ceil_div(k, kRadixThreads);
+    const uint32_t ck_magic = Ck <= 1 ? 0u : (uint32_t)(((1ull << 32) + Ck - 1) / Ck);
+    hipLaunchKernelGGL(k_row_radix, dim3(qc), dim3(kRadixThreads), 0, st, S, bufA, bufB, N, C, c_magic, k, Ck, ck_magic,
+                       select_first, descending, sqrt_out, idx, val, todo);
+    return WV_OK;
+}
+
+// rows per launch of wv_rank_scores: the radix images (16 bytes per score) stay within about 1 GiB
+static int64_t rank_chunk_rows(int Q, int64_t N)
+{
+    const int64_t per_row = ceil_div(N, kRadixThreads) * kRadixThreads * 16;
+    return std::min<int64_t>(std::max<int64_t>((1ll << 30) / std::max<int64_t>(per_row, 1), 1), Q);
+}
+
 static int64_t knn_chunk_rows(int Q, int64_t N)
 {
     // bound the scratch to about 2 GiB: per row N * (4 + 8 + 8) bytes
@@ -867,8 +903,6 @@ extern "C" int wv_knn_float(const float *q, const float *db, int Q, int64_t N, i
         hipLaunchKernelGGL(k_row_sqnorm, dim3((unsigned)ceil_div(Q, 4)), dim3(256), 0, st, q, (int64_t)Q, D, qn);
         hipLaunchKernelGGL(k_row_sqnorm, dim3((unsigned)ceil_div(N, 4)), dim3(256), 0, st, db, N, D, dbn);
     }
-    const int C = (int)ceil_div(N, kRadixThreads);
-    const uint32_t c_magic = C <= 1 ? 0u : (uint32_t)(((1ull << 32) + C - 1) / C);   // exact for pos < 2^32 / C
     const int descending = metric == WV_METRIC_IP;
     const int sqrt_out = metric == WV_METRIC_L2;   // L2 rows are ranked on SQUARED distances (what faiss ranks on; the same
                                                    // order up to ties the rounding of the root creates); the k results get the root
@@ -882,27 +916,44 @@ extern "C" int wv_knn_float(const float *q, const float *db, int Q, int64_t N, i
             hipLaunchKernelGGL(k_scores, grid, dim3(256), 0, st, qf, dbf, qn + q0, dbn, S, qc, N, nchunk, metric);
         else
             hipLaunchKernelGGL(k_scores_lds, grid, dim3(256), 0, st, qf, dbf, qn + q0, dbn, S, qc, N, nchunk, metric);
-        // rows the one-kernel ranking takes never reach the radix kernels (they return at once on todo[row] == 0)
-        const uint8_t *todo = nullptr;
-        if (k + kTkSlack <= kTkCapMax && !::wv::tune("WV_KNN_RADIX_ONLY")) {
-            const int cap = (int)std::min<int64_t>(kTkCapMax, align_up(k + kTkSlack, kTkThreads));
-            int force = ::wv::tune("WV_KNN_FORCE_TODO") ? 1 : 0;   // diagnostic build: every row takes both kernels' hand-over
-            if (const char *stop = ::wv::tune("WV_TK_STOP")) force |= atoi(stop) << 8;
-            const int J = cap / kTkThreads;
-            int rc;
-            if (J <= 2) rc = launch_row_topk<2>(S, N, k, cap, descending, idx + q0 * k, val + q0 * k, todo_buf, force, sqrt_out, qc, st);
-            else if (J <= 4) rc = launch_row_topk<4>(S, N, k, cap, descending, idx + q0 * k, val + q0 * k, todo_buf, force, sqrt_out, qc, st);
-            else if (J <= 8) rc = launch_row_topk<8>(S, N, k, cap, descending, idx + q0 * k, val + q0 * k, todo_buf, force, sqrt_out, qc, st);
-            else rc = launch_row_topk<16>(S, N, k, cap, descending, idx + q0 * k, val + q0 * k, todo_buf, force, sqrt_out, qc, st);
-            if (rc != WV_OK) return rc;
-            todo = todo_buf;
-        }
-        const int select_first = (int64_t)k * 2 <= N && !::wv::tune("WV_KNN_FULLSORT");
-        const int Ck = (int)ceil_div(k, kRadixThreads);
-        const uint32_t ck_magic = Ck <= 1 ? 0u : (uint32_t)(((1ull << 32) + Ck - 1) / Ck);
-        hipLaunchKernelGGL(k_row_radix, dim3(qc), dim3(kRadixThreads), 0, st, S, bufA, bufB, N, C, c_magic, k, Ck, ck_magic,
-                           select_first, descending, sqrt_out, idx + q0 * k, val + q0 * k, todo);
+        const int rc = rank_rows(S, qc, N, k, descending, sqrt_out, idx + q0 * k, val + q0 * k, todo_buf, bufA, bufB, st);
+        if (rc != WV_OK) return rc;
     }
     WV_CHECK_LAUNCH("knn_float");
+    return WV_OK;
+}
+
+extern "C" size_t wv_rank_scores_workspace_bytes(int Q, int64_t N, int k)
+{
+    (void)k;
+    if (Q <= 0 || N <= 0) return 0;
+    const int64_t rows = rank_chunk_rows(Q, N);
+    return (size_t)(rows * ceil_div(N, kRadixThreads) * kRadixThreads * 16 + align_up(rows, 256) + 256);
+}
+
+extern "C" int wv_rank_scores(const float *S, int Q, int64_t N, int k, int flags, int32_t *idx, float *val, void *workspace,
+                              size_t workspace_bytes, void *stream)
+{
+    WV_REQUIRE(S && idx && val, "rank_scores: null buffer");
+    WV_REQUIRE(Q >= 0 && N >= 1, "rank_scores: bad shape Q=%d N=%lld", Q, (long long)N);
+    WV_REQUIRE(k >= 1 && k <= N, "rank_scores: k=%d must be in [1, N=%lld]", k, (long long)N);
+    WV_REQUIRE(N <= (1ll << 26), "rank_scores: N=%lld above the supported 2^26 columns", (long long)N);
+    WV_REQUIRE((flags & ~(WV_RANK_DESCENDING | WV_RANK_SQRT)) == 0, "rank_scores: flags %d", flags);
+    const size_t need = wv_rank_scores_workspace_bytes(Q, N, k);
+    if (!workspace || workspace_bytes < need)
+        WV_FAIL(WV_ENOMEM, "rank_scores: workspace %zu < %zu bytes", workspace_bytes, need);
+    if (Q == 0) return WV_OK;
+    const int64_t rows = rank_chunk_rows(Q, N), pitch = ceil_div(N, kRadixThreads) * kRadixThreads;
+    char *w = (char *)workspace;
+    uint2 *bufA = (uint2 *)w;              w += rows * pitch * 8;
+    uint2 *bufB = (uint2 *)w;              w += rows * pitch * 8;
+    uint8_t *todo_buf = (uint8_t *)w;
+    for (int64_t q0 = 0; q0 < Q; q0 += rows) {
+        const int qc = (int)std::min<int64_t>(rows, Q - q0);
+        const int rc = rank_rows(S + q0 * N, qc, N, k, (flags & WV_RANK_DESCENDING) != 0, (flags & WV_RANK_SQRT) != 0, idx + q0 * k,
+                                 val + q0 * k, todo_buf, bufA, bufB, (hipStream_t)stream);
+        if (rc != WV_OK) return rc;
+    }
+    WV_CHECK_LAUNCH("rank_scores");
     return WV_OK;
 }

@@ -19,6 +19,7 @@ DIAG_LIB_PATH = os.path.join(_HERE, "_lib", "libwvhash_diag.so")
 WV_DT_U8, WV_DT_F32, WV_DT_BF16 = 0, 1, 2
 WV_LAYOUT_NCHW, WV_LAYOUT_NHWC = 0, 1
 WV_METRIC_IP, WV_METRIC_L2, WV_METRIC_L2_SQUARED = 0, 1, 2
+WV_RANK_DESCENDING, WV_RANK_SQRT = 1, 2
 ABI_VERSION = 5        # what include/wvhash.h documents; load() refuses a library that reports another one
 WV_BANDS_INNER, WV_BANDS_OUTER = 0, 1
 
@@ -107,6 +108,9 @@ SIGNATURES = {
     "wv_band_attn_pool": (_i, [ctypes.POINTER(HeadParams), _vp, _i, _vp, _vp, _sz, _vp]),
     "wv_hash_tail": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),
     "wv_knn_float_cpu": (_i, [_vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp]),
+    "wv_rank_scores_workspace_bytes": (_sz, [_i, _i64, _i]),
+    "wv_rank_scores": (_i, [_vp, _i, _i64, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "wv_rank_scores_cpu": (_i, [_vp, _i, _i64, _i, _i, _vp, _vp]),
     "wv_band_attn_pool_cpu": (_i, [ctypes.POINTER(HeadParams), _vp, _i, _vp]),
     "wv_hash_tail_cpu": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
 }

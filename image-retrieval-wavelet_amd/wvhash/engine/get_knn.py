@@ -68,6 +68,27 @@ def knn_float_host(references, queries, num_k, metric):
     return val, idx
 
 
+def rank_scores(scores, k, descending=False, sqrt=False):
+    """The k best columns of every row of a dense fp32 score matrix [Q, N] -- smallest first (descending: largest first), ties
+    by ascending column -- as (values [Q, k], columns int32 [Q, k]); sqrt: the root of the returned values.  The ranking stage
+    of wv_knn_float (wv_rank_scores); CPU tensors take its host twin.  Used to merge per-shard k-NN lists."""
+    s = scores.detach().float().contiguous()
+    Q, N = s.shape
+    flags = (_lib.WV_RANK_DESCENDING if descending else 0) | (_lib.WV_RANK_SQRT if sqrt else 0)
+    idx = torch.empty((Q, k), dtype=torch.int32, device=s.device)
+    val = torch.empty((Q, k), dtype=torch.float32, device=s.device)
+    if not s.is_cuda:
+        _lib.check(_lib.load().wv_rank_scores_cpu(_lib.ptr(s), Q, N, k, flags, _lib.ptr(idx), _lib.ptr(val)), "wv_rank_scores_cpu")
+        return val, idx
+    lib = _lib.require_gpu()
+    ws_bytes = lib.wv_rank_scores_workspace_bytes(Q, N, k)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=s.device)
+    with torch.cuda.device(s.device):
+        _lib.check(lib.wv_rank_scores(_lib.ptr(s), Q, N, k, flags, _lib.ptr(idx), _lib.ptr(val), _lib.ptr(ws),
+                                      ctypes.c_size_t(ws_bytes), _lib.stream_ptr()), "wv_rank_scores")
+    return val, idx
+
+
 def get_knn(references, queries, num_k, embeddings_come_from_same_source, with_faiss=True, distance_metric="l2"):
     num_k += embeddings_come_from_same_source
 

@@ -308,3 +308,68 @@ def exchange_ok(needs, send_hint, kin):
     # (with many ties at the k-th distance the raw count exceeds it although `kin` entries were exchanged: exact)
     worst = min(int(torch.stack([n.reshape(()) for n in needs]).max().item()), int(kin))
     return worst <= max(1, min(int(kin), int(send_hint)))
+
+
+def merge_knn_lists(vals, gidx, k, metric):
+    """Merge of per-shard k-NN lists -- what faiss' sharded index does on the host (get_knn.py:41-44) -- on the device the
+    lists live on.  vals float32 [G, Ql, kk]: every shard's list per query, in ITS ranking order, as inner products
+    (WV_METRIC_IP) or SQUARED distances (both L2 metrics); gidx int32 [G, Ql, kk]: global row numbers; padding entries of a
+    short shard carry the sentinel (-inf for IP, +inf for L2).  Laid side by side in shard order, candidates with equal values
+    are in ascending global row order (a shard ranks ties by ascending row, shard s holds lower rows than shard s + 1), so
+    ranking the candidate matrix with ties by ascending column (wv_rank_scores) gives exactly the unsharded list.
+    -> (values [Ql, k], global rows int32 [Ql, k])."""
+    from . import _lib
+    from .engine.get_knn import rank_scores
+    G, Ql, kk = vals.shape
+    cand = vals.permute(1, 0, 2).reshape(Ql, G * kk).contiguous()
+    rows = gidx.permute(1, 0, 2).reshape(Ql, G * kk)
+    v, pos = rank_scores(cand, k, descending=metric == _lib.WV_METRIC_IP, sqrt=metric == _lib.WV_METRIC_L2)
+    return v, torch.gather(rows, 1, pos.long())
+
+
+def sharded_knn_float(q_local, db_shard, k, metric, n_total, group=None):
+    """Real-valued k-NN over a row-sharded database, one process per GPU: the role faiss.index_cpu_to_all_gpus(shards=True)
+    plays for IndexFlatIP / IndexFlatL2 in the reference (main/engine/get_knn.py:35-52).  q_local [Ql, D]: THIS rank's
+    queries (every rank the same Ql); db_shard: rows [rank * per, ...) of the database, per = ceil(n_total / world).
+    One all_gather of the queries, wv_knn_float on the shard for everybody's queries, one all_to_all of the per-shard lists
+    (value bits and global row packed into 8 bytes per entry), merge_knn_lists.  Results are those of wv_knn_float on the
+    whole database, bit for bit, for every world size.  Host tensors (gloo) take the library's host twins.
+    -> (values [Ql, k], global rows int32 [Ql, k])."""
+    from . import _lib
+    from .engine.get_knn import knn_float, knn_float_host
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    per = (n_total + world - 1) // world
+    lo = min(n_total, rank * per)
+    if k > n_total:
+        raise RuntimeError(f"selected index k out of range (k={k}, references={n_total})")
+    q_local = q_local.float().contiguous()
+    Ql, D = q_local.shape
+    dev = q_local.device
+    q_all = torch.empty((world * Ql, D), dtype=torch.float32, device=dev)
+    if world > 1:
+        _all_gather(q_all, q_local, group)
+    else:
+        q_all.copy_(q_local)
+    kk = min(k, per)
+    n_loc = db_shard.shape[0]
+    shard_metric = _lib.WV_METRIC_IP if metric == _lib.WV_METRIC_IP else _lib.WV_METRIC_L2_SQUARED
+    sentinel = float("-inf") if metric == _lib.WV_METRIC_IP else float("inf")
+    vals = torch.full((world * Ql, kk), sentinel, dtype=torch.float32, device=dev)
+    rows = torch.full((world * Ql, kk), -1, dtype=torch.int32, device=dev)
+    k_loc = min(kk, n_loc)
+    if k_loc:
+        v, i = (knn_float if dev.type == "cuda" else knn_float_host)(db_shard, q_all, k_loc, shard_metric)
+        vals[:, :k_loc] = v
+        rows[:, :k_loc] = i + lo
+    # one 8-byte word per entry: value bits | global row
+    send = (vals.view(torch.int32).long() << 32) | (rows.long() & 0xFFFFFFFF)
+    recv = torch.empty_like(send)
+    if world > 1:
+        _all_to_all(recv, send.contiguous(), group)      # [shard, Ql, kk] of this rank's queries
+    else:
+        recv = send
+    recv = recv.view(world, Ql, kk)
+    got_v = (recv >> 32).int().view(torch.float32)
+    got_i = (recv & 0xFFFFFFFF).int()
+    return merge_knn_lists(got_v, got_i, k, metric)

@@ -44,8 +44,8 @@ extern "C" {
 #define WV_LAYOUT_NHWC 1 /* [B][H][W][C]  (PIL / numpy, what np.array(img) yields) */
 
 const char *wv_last_error(void);
-/* 5 = this header.  History: 5 added WV_METRIC_L2_SQUARED and the host twins wv_knn_float_cpu, wv_band_attn_pool_cpu,
- * wv_hash_tail_cpu; 4 added the host twins of the ranking side (wv_pack_bits_cpu ... wv_hit_prefix_cpu); 2 added wv_head_params.q_proj, the host twins, wv_swt2d_forward_ex, the two-step shard entry
+/* 5 = this header.  History: 5 added WV_METRIC_L2_SQUARED, wv_rank_scores[_cpu] and the host twins wv_knn_float_cpu,
+ * wv_band_attn_pool_cpu, wv_hash_tail_cpu; 4 added the host twins of the ranking side (wv_pack_bits_cpu ... wv_hit_prefix_cpu); 2 added wv_head_params.q_proj, the host twins, wv_swt2d_forward_ex, the two-step shard entry
  * points and wv_map_at_k_ld; 3 added wv_head_params.prepared / wv_band_attn_prepare (one-launch head front), the ranking + AP
  * entry points (wv_hamming_map_at_k, wv_rank_labels_prepare), wv_hamming_shard_prefix / wv_topk_merge_cum_need and the
  * relevance-string pair of the sharded mAP (wv_hamming_shard_relbits, wv_merge_relbits_map).  A struct gaining a field bumps it. */
@@ -329,6 +329,19 @@ int wv_knn_float(const float *q, const float *db, int Q, int64_t N, int D, int m
  * v_mfma_f32_32x32x2_f32 is an fmaf chain (k = 0 before k = 1; tools/mfma_order_test.hip), the twin walks k in the order
  * the kernel feeds it, forms the squared norms in the kernel's lane / butterfly order and ranks on the same keys. */
 int wv_knn_float_cpu(const float *q, const float *db, int Q, int64_t N, int D, int metric, int k, int32_t *idx, float *val);
+
+/* The ranking stage of wv_knn_float on scores the caller made: per row of S [Q][N] (dense) the k best columns, smallest
+ * first (WV_RANK_DESCENDING: largest first), ties by ascending column -- idx int32 [Q][k] column numbers, val float32
+ * [Q][k] their scores (WV_RANK_SQRT: the root of them, for squared distances).  It is the merge of per-shard k-NN lists
+ * that faiss' sharded index does on the host (get_knn.py:41-44): the shards' (value, global row) lists laid side by side in
+ * shard order rank to exactly the unsharded result (wvhash.parallel.sharded_knn_float).  Host twin: same arguments, host
+ * pointers, no workspace / stream. */
+#define WV_RANK_DESCENDING 1
+#define WV_RANK_SQRT 2
+size_t wv_rank_scores_workspace_bytes(int Q, int64_t N, int k);
+int wv_rank_scores(const float *S, int Q, int64_t N, int k, int flags, int32_t *idx, float *val, void *workspace,
+                   size_t workspace_bytes, void *stream);
+int wv_rank_scores_cpu(const float *S, int Q, int64_t N, int k, int flags, int32_t *idx, float *val);
 
 /* ------------------------------------------------------------------------------------------
  * Band-attention pooling head + hashing tail (eval mode).

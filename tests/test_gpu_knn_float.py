@@ -149,3 +149,46 @@ def test_host_twin_equals_the_kernels_bit_for_bit(D):
         vh, ih = knn_float_host(r, q, k, metric)
         assert torch.equal(ig.cpu(), ih), metric
         assert torch.equal(vg.cpu().view(torch.int32), vh.view(torch.int32)), metric
+
+
+@pytest.mark.parametrize("Q,N,k,flags", [(37, 5000, 300, 0), (5, 20000, 20000, _lib.WV_RANK_DESCENDING), (9, 70, 70, _lib.WV_RANK_SQRT),
+                                         (3, 40000, 15360, _lib.WV_RANK_DESCENDING), (1, 1, 1, 0)])
+def test_rank_scores_is_the_stable_order_of_a_given_matrix(Q, N, k, flags):
+    """wv_rank_scores: the ranking stage of wv_knn_float on scores the caller made (the merge step of the sharded search).
+    Quantised scores (many ties) against torch's stable sort; the host twin gives the same."""
+    from wvhash.engine.get_knn import rank_scores
+    g = torch.Generator().manual_seed(N + k)
+    s = (torch.randn(Q, N, generator=g) * 4).round().abs() / 4 if flags & _lib.WV_RANK_SQRT else (torch.randn(Q, N, generator=g) * 8).round() / 8
+    desc, root = bool(flags & _lib.WV_RANK_DESCENDING), bool(flags & _lib.WV_RANK_SQRT)
+    v, i = rank_scores(s.cuda(), k, descending=desc, sqrt=root)
+    order = torch.argsort(s, dim=1, descending=desc, stable=True)[:, :k]
+    want = torch.gather(s, 1, order)
+    assert torch.equal(i.cpu().long(), order)
+    assert torch.equal(v.cpu(), want.sqrt() if root else want) or torch.allclose(v.cpu(), want.sqrt(), rtol=3e-7, atol=0)
+    vh, ih = rank_scores(s, k, descending=desc, sqrt=root)
+    assert torch.equal(ih, i.cpu()) and torch.equal(vh.view(torch.int32), v.cpu().view(torch.int32))
+
+
+def test_shard_lists_merge_to_the_unsharded_search():
+    """merge_knn_lists on one GPU: G = 2 ... 8 shards ranked one after the other, their lists laid side by side and ranked
+    again -- the unsharded wv_knn_float lists bit for bit (ties across shards: duplicated rows; ragged last shard)."""
+    from wvhash import parallel
+    g = torch.Generator().manual_seed(8)
+    Q, N, D, k = 21, 9001, 32, 1500
+    q, r = torch.randn(Q, D, generator=g).cuda(), torch.randn(N, D, generator=g).cuda()
+    r[N // 2:N // 2 + 64] = r[:64].clone()
+    for metric in (IP, L2, _lib.WV_METRIC_L2_SQUARED):
+        v0, i0 = knn_float(r, q, k, metric)
+        for G in (2, 3, 8):
+            per = (N + G - 1) // G
+            kk = min(k, per)
+            sm = IP if metric == IP else _lib.WV_METRIC_L2_SQUARED
+            V = torch.full((G, Q, kk), float("-inf") if metric == IP else float("inf"), device="cuda")
+            I = torch.full((G, Q, kk), -1, dtype=torch.int32, device="cuda")
+            for s in range(G):
+                sh = r[s * per:(s + 1) * per]
+                kl = min(kk, sh.shape[0])
+                v, i = knn_float(sh, q, kl, sm)
+                V[s, :, :kl], I[s, :, :kl] = v, i + s * per
+            v, i = parallel.merge_knn_lists(V, I, k, metric)
+            assert torch.equal(i, i0) and torch.equal(v.view(torch.int32), v0.view(torch.int32)), (metric, G)

@@ -169,3 +169,38 @@ def test_single_gpu_bench_line_carries_the_untuned_number_and_no_host_sync():
     assert rec["value_first_allocation"] > 0 and rec["first_allocation"]["ms_per_step"] > 0
     assert rec["config"]["host_syncs_in_timed_steps"] == 0
     assert rec["roofline"]["frac"] > 0 and rec["config"]["swt_output_placement"]["candidates"] >= 1
+
+
+# ----------------------------------------------------------------------------------------- real-valued k-NN, row-sharded
+def _knn_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "image-retrieval-wavelet_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wvhash import parallel, _lib
+    from wvhash.engine.get_knn import knn_float
+    ok = {}
+    for n_db, D, ql, k in ((25000, 64, 48, 5000), (1001, 20, 5, 700), (40000, 384, 9, 100)):
+        g = torch.Generator().manual_seed(n_db)
+        q_all, r = torch.randn(world * ql, D, generator=g), torch.randn(n_db, D, generator=g)
+        r[n_db // 2:n_db // 2 + 40] = r[:40].clone()              # ties that straddle the shards
+        lo, hi, _ = parallel.shard_bounds(n_db, world, rank)
+        mine = q_all[rank * ql:(rank + 1) * ql].cuda()
+        for metric in (_lib.WV_METRIC_IP, _lib.WV_METRIC_L2, _lib.WV_METRIC_L2_SQUARED):
+            v, i = parallel.sharded_knn_float(mine, r[lo:hi].cuda(), k, metric, n_db)
+            v0, i0 = knn_float(r.cuda(), mine, k, metric)
+            ok[(n_db, metric)] = torch.equal(i, i0) and torch.equal(v.view(torch.int32), v0.view(torch.int32))
+    torch.save(ok, os.path.join(out_dir, f"knn{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_sharded_float_knn_real_kernels(tmp_path):
+    """wvhash.parallel.sharded_knn_float with wv_knn_float and wv_rank_scores on both ranks (one GPU, gloo staging): the merged
+    lists equal the unsharded search bit for bit, every metric, k above a shard's share (5000 of 12,500 rows) and below."""
+    port = 34100 + os.getpid() % 2000
+    mp.spawn(_knn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        ok = torch.load(os.path.join(tmp_path, f"knn{rank}.pt"))
+        assert len(ok) == 9 and all(ok.values()), ok

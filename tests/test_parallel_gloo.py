@@ -276,3 +276,56 @@ def test_shard_bounds_cover_the_database():
         spans = [shard_bounds(n, w, r)[:2] for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+
+
+# ----------------------------------------------------------------------------------------- real-valued k-NN, row-sharded
+def _knn_worker(rank, world, port, n_db, D, ql, ks, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "image-retrieval-wavelet_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wvhash import parallel, _lib
+    g = torch.Generator().manual_seed(17)
+    q_all, r = torch.randn(world * ql, D, generator=g), torch.randn(n_db, D, generator=g)
+    dup = min(40, n_db // 2)
+    r[n_db // 2:n_db // 2 + dup] = r[:dup].clone()                # duplicated rows: ties that straddle shards
+    q_all[1] = r[3]                                               # an exact match (squared distance 0)
+    lo, hi, _ = parallel.shard_bounds(n_db, world, rank)
+    out = {}
+    parallel.TRACE = parallel.ExchangeTrace()
+    for k in ks:
+        for metric in (_lib.WV_METRIC_IP, _lib.WV_METRIC_L2, _lib.WV_METRIC_L2_SQUARED):
+            out[(k, metric)] = parallel.sharded_knn_float(q_all[rank * ql:(rank + 1) * ql], r[lo:hi], k, metric, n_db)
+    calls = dict(parallel.TRACE.calls)
+    parallel.TRACE = None
+    assert calls == {"all_gather": 3 * len(ks), "all_to_all": 3 * len(ks), "all_reduce": 0}, calls
+    torch.save(out, os.path.join(out_dir, f"knn{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_db", [(2, 1001), (3, 700), (3, 7)])
+def test_sharded_float_knn_equals_unsharded(tmp_path, world, n_db):
+    """wvhash.parallel.sharded_knn_float (faiss' sharded IndexFlatIP / IndexFlatL2, get_knn.py:35-52) over real gloo ranks
+    with the library's host twins: one all_gather + one all_to_all per call, and the merged lists equal wv_knn_float_cpu on
+    the whole database bit for bit -- k below and above a shard's rows, a ragged (or empty) last shard, ties across shards."""
+    sys.path.insert(0, os.path.join(ROOT, "image-retrieval-wavelet_amd"))
+    from wvhash import _lib
+    from wvhash.engine.get_knn import knn_float_host
+    D, ql = 12, 4
+    ks = [1, min(5, n_db), min(400, n_db), n_db]
+    port = 33600 + (os.getpid() + world * 13 + n_db) % 2000
+    mp.spawn(_knn_worker, args=(world, port, n_db, D, ql, ks, str(tmp_path)), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(17)
+    q_all, r = torch.randn(world * ql, D, generator=g), torch.randn(n_db, D, generator=g)
+    dup = min(40, n_db // 2)
+    r[n_db // 2:n_db // 2 + dup] = r[:dup].clone()
+    q_all[1] = r[3]
+    for rank in range(world):
+        got = torch.load(os.path.join(tmp_path, f"knn{rank}.pt"))
+        for k in ks:
+            for metric in (_lib.WV_METRIC_IP, _lib.WV_METRIC_L2, _lib.WV_METRIC_L2_SQUARED):
+                v0, i0 = knn_float_host(r, q_all[rank * ql:(rank + 1) * ql], k, metric)
+                v, i = got[(k, metric)]
+                assert torch.equal(i, i0), (rank, k, metric)
+                assert torch.equal(v.view(torch.int32), v0.view(torch.int32)), (rank, k, metric)
