@@ -259,7 +259,8 @@ def evaluate_sharded(net, test_dataset, k=5000, epoch=None, batch_size=64, num_w
       most 32,768 rows: MIRFLICKR and COCO at k = 5000; otherwise lists are exchanged, the packed database labels
       all-gathered (8 bytes per row and label word) and AP computed from the merged lists: the same numbers;
     * the AP sums and the per-bit counts are all-reduced.
-    Returns ``{"test": {"epoch", "maphashing_level0", "bit_balance_level0", "worst_bit_balance_level0"}}``, the same
+    Returns ``{"test": {"epoch", "maphashing_level0", "map_level0", "bit_balance_level0", "worst_bit_balance_level0"}}`` -- the
+    four columns evaluate_all_checkpoints.py:173-174 reads into its CSVs --, the same
     numbers as evaluate() on one GPU (lists are identical for every world size; AP sums differ by fp64 rounding only).
     Every rank's query slice is padded to a common length by repeating its last query; the copies are not counted."""
     import torch.distributed as dist
@@ -326,15 +327,34 @@ def evaluate_sharded(net, test_dataset, k=5000, epoch=None, batch_size=64, num_w
         # global row g of shard s sits at row s * per_db + (g - lo_s) of the gathered label table = g (shards are contiguous
         # slices of equal length per_db, the last one shorter): the gathered table is indexed by the global row directly
         ap, _ = H.map_at_k(idx, qlp, rlp_all)
-    sums = torch.zeros(2 + nbits, dtype=torch.float64, device=dev)
+    # map_level0 (calculate_map, accuracy_calculator.py:156-167): the same average precisions, averaged over the queries
+    # that are not "lone" -- at least one database row anywhere shares a label with them (a lone query's AP is 0, so the
+    # numerator is the one of maphashing).  Every rank tests all queries' label words against its shard's; MAX-reduced.
+    if world > 1:
+        ql_all = torch.empty((world * q_per, lw), dtype=torch.int64, device=dev)
+        _all_gather(ql_all, qlp.contiguous(), group)
+    else:
+        ql_all = qlp
+    has = torch.zeros(ql_all.shape[0], dtype=torch.int32, device=dev)
+    shard_lab = rlp_local[:hi - lo]
+    if hi > lo:
+        for s in range(0, ql_all.shape[0], 256):
+            has[s:s + 256] = ((ql_all[s:s + 256, None, :] & shard_lab[None, :, :]) != 0).any(-1).any(1).int()
+    if world > 1:
+        _all_reduce(has, dist.ReduceOp.MAX, group)
+    not_lone = has[rank * q_per:rank * q_per + n_local_q] if world > 1 else has[:n_local_q]
+    sums = torch.zeros(3 + nbits, dtype=torch.float64, device=dev)
     sums[0] = ap[:n_local_q].double().sum()
     sums[1] = float(hi - lo)
+    sums[2] = not_lone.double().sum()
     if hi > lo:
-        sums[2:] = H.bit_counts(rp, nbits).double()
+        sums[3:] = H.bit_counts(rp, nbits).double()
     if world > 1:
         _all_reduce(sums, dist.ReduceOp.SUM, group)
-    frac = sums[2:] / sums[1]
+    frac = sums[3:] / sums[1]
     balance = 1.0 - 2.0 * (frac - 0.5).abs()
+    kept = float(sums[2].item())
     return {"test": {"epoch": f"{epoch}", "maphashing_level0": float(sums[0].item()) / n_q,
+                     "map_level0": float(sums[0].item()) / kept if kept else 0.0,
                      "bit_balance_level0": float(balance.mean().item()),
                      "worst_bit_balance_level0": float(balance.min().item())}}
