@@ -114,7 +114,10 @@ def test_deferred_transform_only_sizes_the_image():
 def test_wavelet_table_matches_oracle_table():
     from oracle import swt_np
     from wvhash.transforms import get_filters, wavelist
+    from wvhash.transforms.wavelets import _COMPUTED_NAMES, _daubechies
     for name in wavelist():
+        if name in _COMPUTED_NAMES:
+            continue                                  # computed orders: next test
         lo, hi = get_filters(name)
         olo, ohi = swt_np.filters(name)
         np.testing.assert_array_equal(lo, olo)
@@ -122,6 +125,35 @@ def test_wavelet_table_matches_oracle_table():
     with pytest.raises(ValueError):
         get_filters("nope")
     assert get_filters(([1, 2], [3, 4])) == ([1.0, 2.0], [3.0, 4.0])
+    # the routine behind the computed orders reproduces the tabulated (PyWavelets) db2 / db4
+    for n, name in ((2, "db2"), (4, "db4")):
+        np.testing.assert_allclose(_daubechies(n), get_filters(name)[0], rtol=0, atol=1e-12)
+
+
+def test_computed_daubechies_orders_are_orthonormal_with_n_vanishing_moments():
+    """db3, db5 ... db10 are not in the reference's configs; they are computed (spectral factorisation, extremal phase).
+    What defines them: 2N taps, sum sqrt(2), unit energy, orthogonal to their even shifts, N vanishing moments of the
+    high-pass filter; db3 also against its published taps.  And they run through the transform's host twin."""
+    from PIL import Image
+    from wvhash.transforms import SWTTransform, get_filters
+    db3 = [0.035226291882100656, -0.08544127388224149, -0.13501102001039084, 0.4598775021193313, 0.8068915093133388,
+           0.3326705529509569]
+    np.testing.assert_allclose(get_filters("db3")[0], db3, rtol=0, atol=1e-11)
+    for n in (3, 5, 6, 7, 8, 9, 10):
+        lo, hi = (np.array(v) for v in get_filters(f"db{n}"))
+        L = len(lo)
+        assert L == 2 * n and abs(lo.sum() - 2 ** 0.5) < 1e-12 and abs((lo * lo).sum() - 1) < 1e-12 and abs(hi.sum()) < 1e-9
+        for m in range(1, n):
+            assert abs((lo[: L - 2 * m] * lo[2 * m:]).sum()) < 1e-12
+        k = np.arange(L, dtype=np.float64)
+        for p in range(n):                                          # moments of the high-pass filter, relative to their scale
+            assert abs((hi * k ** p).sum()) < 1e-9 * max(1.0, (np.abs(hi) * k ** p).sum()), (n, p)
+    img = Image.fromarray(np.random.default_rng(0).integers(0, 256, (32, 32, 3)).astype(np.uint8))
+    x = np.asarray(img, np.float64).transpose(2, 0, 1) / 255.0
+    for name in ("db3", "db6"):
+        out = SWTTransform(level=1, wavelet=name, device="cpu")(img).double().numpy()     # [3, 4, 32, 32]
+        # undecimated, orthonormal, periodic: the four level-1 bands carry 4 x the energy of the image
+        np.testing.assert_allclose((out ** 2).sum(axis=(1, 2, 3)), 4 * (x ** 2).sum(axis=(1, 2)), rtol=1e-5)
 
 
 def test_plain_c_program_runs_the_host_twins_without_a_gpu():

@@ -176,3 +176,14 @@ def test_placed_output_buffer_is_a_plain_result_buffer():
     assert torch.equal(buf, swt2d(img, "db2", 2, channels_last=True))
     bm, info1 = swt2d_place_output(img, "haar", 1, channels_last=True, band_major=True, candidates=1)
     assert tuple(bm.shape) == (4, 8, 3, 64, 64) and info1["probe_ms"] == []
+
+
+@pytest.mark.parametrize("name,lev", [("db3", 2), ("db6", 1), ("db10", 1)])
+def test_computed_daubechies_names_run_through_the_generic_kernels(name, lev):
+    """db3, db5 ... db10 (computed taps, wvhash/transforms/wavelets.py) have no tiled / sliding instantiation: the generic
+    kernels take them; against the oracle on the same taps."""
+    from wvhash.transforms import get_filters
+    img = synth.natural_images(2, 64, 64, seed=len(name) + lev)
+    ref = swt_np.c_transform_batch(img, get_filters(name), lev)
+    got = run_hip(img, name, lev, False).cpu().numpy()
+    assert got.shape == (2, 3, 4, 64, 64) and np.abs(got - ref).max() <= tol(lev)
